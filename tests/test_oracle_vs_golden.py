@@ -1,0 +1,71 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/ref_*.npz,
+written by oracle/make_golden.py from /root/reference's own VisualCLAModel)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import visualcla_oracle as O
+
+CASES = {"tiny_b2": O.cfg_tiny, "small_b2": O.cfg_small}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_taps(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"ref_{name}.npz"))
+    cfg = CASES[name]()
+    B, T, n_new = (int(x) for x in g["_meta"])
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, B, T)
+    assert np.array_equal(ids.numpy(), g["_input_ids"])
+    taps = {}
+    logits = O.visualcla_forward(ids, px, mask, W, cfg, taps=taps)
+    checked = 0
+    for k in g.files:
+        if k.startswith("_") or k == "generated":
+            continue
+        ref = torch.from_numpy(g[k])
+        got = taps[k].float()
+        assert got.shape == ref.shape, k
+        err = (got - ref).abs().max().item()
+        # fp32 restatement vs fp32 reference: only summation-order noise is allowed
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (k, err)
+        checked += 1
+    assert checked >= 8
+    assert torch.allclose(logits, torch.from_numpy(g["logits"]), atol=2e-5)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_greedy_generate_matches_reference(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"ref_{name}.npz"))
+    cfg = CASES[name]()
+    B, T, n_new = (int(x) for x in g["_meta"])
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, B, T)
+    toks = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=n_new)
+    assert toks.shape == (B, n_new)
+    assert np.array_equal(toks.numpy(), g["generated"])
+
+
+def test_splice_error_convention():
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 1, 24)
+    bad = ids.clone()
+    p0 = int((bad[0] == cfg.img_start_token_id).nonzero()[0])
+    bad[0, p0 + cfg.resampler.num_query_tokens + 1] = 5       # </img> missing
+    with pytest.raises(ValueError):
+        O.visualcla_forward(bad, px, mask, W, cfg)
+
+
+def test_kv_cache_decode_equals_full_forward():
+    """size-independent property: prefill+decode logits == full-sequence forward logits."""
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 2, 24)
+    toks, step_logits = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=3, return_logits=True)
+    full_ids = torch.cat([ids, toks[:, :2]], dim=1)
+    full = O.visualcla_forward(full_ids, px, torch.ones_like(full_ids), W, cfg)
+    for s in range(3):
+        assert torch.allclose(step_logits[s], full[:, ids.shape[1] - 1 + s], atol=1e-4)
