@@ -1,0 +1,219 @@
+/*
+ * visualcla_hip.h -- C ABI of libvisualcla_hip.so: the MI355X (gfx950) hot path of
+ * VisualCLA (CLIP-ViT-L/14 -> Resampler -> projection -> LLaMA decoder -> LM head).
+ *
+ * Boundary contract:
+ *   - plain pointers + sizes, no torch types.  All device buffers (weights, activations,
+ *     KV cache, workspace) are allocated and owned by the caller (PyTorch-ROCm); the
+ *     library never allocates/frees device memory and never synchronises: every entry
+ *     point enqueues work on the given hipStream_t (passed as void*) and returns.
+ *   - every function returns an int status (VCLA_OK = 0); vcla_last_error() gives the
+ *     text of the last failure on the calling thread.  Never abort()s.
+ *   - callable from any host thread (chat_in_stream runs generate() in a worker thread,
+ *     models/visualcla/modeling_utils.py:215-225); one vcla_ctx is used by one thread at
+ *     a time.
+ *
+ * "act dtype": VCLA_BF16 = bf16 activations / fp32 accumulate (the product path);
+ * VCLA_F32 = fp32 activations (the algorithmic-parity test mode, checked at 1e-3
+ * against the fp32 CPU oracle).  GEMM weights are bf16 in both modes; small vectors
+ * (biases, norm gains, class/position embeddings, RoPE tables) are fp32.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference;
+ * hf: = the pinned third-party dependency transformers, setup.py:13):
+ *   vcla_layernorm          torch.nn.LayerNorm call sites hf:clip/modeling_clip.py:368,377,642;
+ *                           models/visualcla/modeling_visualcla.py:284,350;
+ *                           models/visualcla/modeling_visual_resampler.py:276,356
+ *   vcla_rmsnorm            LlamaRMSNorm.forward hf:llama/modeling_llama.py:62-67
+ *   vcla_gemm               every nn.Linear on the path (hf:clip/modeling_clip.py:280-282,332,345-347;
+ *                           modeling_visual_resampler.py:174,187-188,274,341,354;
+ *                           modeling_visualcla.py:288,354; hf:llama/modeling_llama.py:175,250-252,280,480)
+ *                           with the activation / residual fused (quick_gelu, erf-gelu, SiLU*up)
+ *   vcla_im2col             the patch-embedding Conv2d hf:clip/modeling_clip.py:209 (as GEMM operand)
+ *   vcla_vit_assemble       class/position embedding + pre_layrnorm hf:clip/modeling_clip.py:211-218,642
+ *   vcla_attention          eager_attention_forward hf:clip/modeling_clip.py:259-277,
+ *                           hf:llama/modeling_llama.py:191-214; modeling_visual_resampler.py:213-253
+ *   vcla_embed_splice       embed_tokens + image splice modeling_visualcla.py:280,292-305 / :346,358-370
+ *   vcla_rope_kv_append     apply_rotary_pos_emb + cache update hf:llama/modeling_llama.py:130-160,255-259
+ *   vcla_argmax             greedy token selection hf:generation/utils.py (argmax over fp32 logits)
+ *   vcla_vision_forward     modeling_visualcla.py:283-288 / :349-354 (and tgwebui embed_images,
+ *                           scripts/inference/text_generation_webui/visualcla/visualcla.py:116-129)
+ *   vcla_llama_prefill      LlamaForCausalLM.forward over the spliced embeds, modeling_visualcla.py:321-328
+ *   vcla_llama_decode_step  one iteration of the HF generate loop, modeling_visualcla.py:382-391
+ */
+#ifndef VISUALCLA_HIP_H
+#define VISUALCLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCLA_ABI_VERSION 1
+
+/* status codes */
+enum {
+    VCLA_OK = 0,
+    VCLA_ERR_BAD_SHAPE = 1,
+    VCLA_ERR_BAD_DTYPE = 2,
+    VCLA_ERR_UNSUPPORTED_ARCH = 3,
+    VCLA_ERR_HIP = 4,
+    VCLA_ERR_BAD_ARG = 5,
+    VCLA_ERR_WORKSPACE = 6,
+    VCLA_ERR_MISSING_TENSOR = 7
+};
+
+/* activation dtypes */
+enum { VCLA_F32 = 0, VCLA_BF16 = 1 };
+
+/* GEMM epilogues (applied to acc + bias) */
+enum {
+    VCLA_EPI_NONE = 0,
+    VCLA_EPI_QUICK_GELU = 1, /* x * sigmoid(1.702 x)            (CLIP MLP)        */
+    VCLA_EPI_GELU_ERF = 2,   /* 0.5 x (1 + erf(x / sqrt 2))     (resampler FFN)   */
+    VCLA_EPI_SWIGLU = 3      /* silu(gate) * up; W rows interleaved in blocks of 16
+                                (16 gate rows, 16 up rows, ...); output width N/2  */
+};
+
+int vcla_version(void);
+const char* vcla_last_error(void);
+/* 0 if the current device is a gfx950 and kernels can launch; else an error code. */
+int vcla_device_check(void);
+
+/* ---------------------------------------------------------------- primitives */
+
+/* y[r,:] = LN(x[r,:]) * gamma + beta        rows x cols, row strides ldx/ldy (elements) */
+int vcla_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                   int rows, int cols, float eps, int dtype, void* stream);
+
+/* y[r,:] = gamma * round_to_dtype(x[r,:] * rsqrt(mean(x^2) + eps)) */
+int vcla_rmsnorm(const void* x, int64_t ldx, const float* gamma, void* y, int64_t ldy, int rows, int cols,
+                 float eps, int dtype, void* stream);
+
+typedef struct vcla_gemm_args {
+    const void* A;        /* [M, K] activations, row stride lda (elements)                     */
+    int64_t lda;
+    const void* W;        /* [N_pad, K] bf16, K contiguous; N_pad = N rounded up to 128 rows    */
+    const float* bias;    /* [N] or NULL                                                        */
+    const void* residual; /* [M, N_out] act dtype, row stride ldr, added last; or NULL          */
+    int64_t ldr;
+    void* C;              /* [M, N_out], row stride ldc                                         */
+    int64_t ldc;
+    int M, N, K;          /* K % 64 == 0; N = rows of W actually used (SWIGLU: N_out = N/2)     */
+    int epilogue;         /* VCLA_EPI_*                                                         */
+    int out_f32;          /* 1: C is fp32 even when dtype == VCLA_BF16 (logits)                 */
+    /* output row remap: row m is stored at row (m / c_group_rows) * c_group_stride +
+       (m % c_group_rows) + c_row_offset of C (c_group_rows == 0: identity)                    */
+    int c_group_rows, c_group_stride, c_row_offset;
+    int force_kernel;     /* 0 auto; 1 MFMA tile kernel; 2 row-streaming GEMV kernel; 3 fp32 tile */
+} vcla_gemm_args;
+
+/* C = epilogue(A . W^T + bias) (+ residual) */
+int vcla_gemm(const vcla_gemm_args* args, int dtype, void* stream);
+
+/* pixel_values [B, C, H, W] -> patches [B * (H/P) * (W/P), k_pad]; column order (c, ky, kx), zero padded */
+int vcla_im2col(const void* pixels, void* patches, int B, int C, int H, int W, int P, int k_pad, int dtype,
+                void* stream);
+
+/* x[b, 0] = cls + pos[0]; x[b, 1+p] = patch[b*np + p] + pos[1+p]; then LayerNorm(gamma, beta)  -> y [B*(np+1), D] */
+int vcla_vit_assemble(const void* patch_embeds, const float* cls, const float* pos, const float* gamma,
+                      const float* beta, void* y, int B, int np, int D, float eps, int dtype, void* stream);
+
+typedef struct vcla_attn_args {
+    const void *q, *k, *v;
+    void* o;
+    /* element (b, h, i, d) of X sits at X[b * x_bs + h * x_hs + i * x_rs + d]  (strides in elements) */
+    int64_t q_bs, q_hs, q_rs;
+    int64_t k_bs, k_hs, k_rs;
+    int64_t v_bs, v_hs, v_rs;
+    int64_t o_bs, o_hs, o_rs;
+    int B, H, Tq, Tk, D; /* D in {32, 64, 128} */
+    float scale;
+    int causal;             /* 1: query i attends keys j <= i + (Tk - Tq)                            */
+    const int32_t* key_mask; /* [B, key_mask_ld] 1 = attend, 0 = masked; or NULL                      */
+    int64_t key_mask_ld;
+    const int32_t* tk_dev;  /* optional device scalar: effective Tk = *tk_dev + tk_dev_add (Tq = 1)  */
+    int tk_dev_add;
+    int force_kernel;       /* 0 auto; 1 generic (fp32 math) kernel; 2 MFMA flash kernel            */
+} vcla_attn_args;
+
+/* o = softmax(scale * q k^T + mask) v */
+int vcla_attention(const vcla_attn_args* args, int dtype, void* stream);
+
+/* out[b, t] = table[ids[b, t]], except rows img_pos[b]+1 .. img_pos[b]+Q which take image_embeds[b, :]
+   (img_pos[b] < 0: no image in that sample).  table is bf16 [V, D]. */
+int vcla_embed_splice(const int64_t* ids, const void* table, const void* image_embeds, const int32_t* img_pos,
+                      void* out, int B, int T, int Q, int D, int V, int dtype, void* stream);
+
+/* RoPE on q (in place) and k of a fused qkv buffer [B*T, 3*H*d], append k / v to the cache.
+   position of row t = pos0 + (pos_dev ? *pos_dev : 0) + t.  cos/sin tables fp32 [max_pos, d/2].
+   k_cache / v_cache: [B, H, ctx_max, d]. */
+int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
+                        int B, int T, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev, int dtype,
+                        void* stream);
+
+/* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
+int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);
+
+/* ---------------------------------------------------------------- model context */
+
+typedef struct vcla_model_cfg {
+    int act_dtype; /* VCLA_F32 | VCLA_BF16 */
+    /* vision tower */
+    int v_hidden, v_layers, v_heads, v_inter, v_patch, v_image, v_channels;
+    float v_eps;
+    /* resampler */
+    int r_hidden, r_layers, r_heads, r_inter, r_queries;
+    float r_eps;
+    /* text decoder */
+    int t_hidden, t_layers, t_heads, t_inter, t_vocab, t_max_pos;
+    float t_eps;
+    float t_rope_theta;
+} vcla_model_cfg;
+
+typedef struct vcla_ctx vcla_ctx;
+
+int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out);
+void vcla_ctx_destroy(vcla_ctx* ctx);
+/* Register a caller-owned device tensor under a name (see csrc/engine.cpp for the list:
+   "vit.patch_w", "vit.l3.wqkv", "llama.l0.wgu", ...).  The caller keeps the memory alive. */
+int vcla_ctx_set_tensor(vcla_ctx* ctx, const char* name, const void* ptr, size_t nbytes);
+/* Checks that every tensor the config needs is registered with the right size. */
+int vcla_ctx_finalize(vcla_ctx* ctx);
+
+size_t vcla_vision_workspace_bytes(const vcla_ctx* ctx, int B);
+size_t vcla_llama_workspace_bytes(const vcla_ctx* ctx, int B, int T);
+size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max);
+
+/* pixel_values [B, C, H, W] (act dtype) -> image_embeds [B, Q, t_hidden].
+   Optional taps (act dtype, may be NULL): vit_tap [v_layers + 1][B * N * v_hidden]
+   (post-LN output last), res_tap [r_layers][B * Q * r_hidden]. */
+int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws,
+                        size_t ws_bytes, void* vit_tap, void* res_tap, void* stream);
+
+/* Decoder over inputs_embeds [B, T, t_hidden] at positions pos0 .. pos0+T-1; fills the KV cache
+   ([L][2][B][H][ctx_max][d]).  logits (fp32): all_logits != 0 -> [B, T, V] else last position only [B, V].
+   key_mask: optional [B, ctx_max] int32.  layer_tap: optional [L + 1][B*T*hidden] (final-norm output last). */
+int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache,
+                       int ctx_max, const int32_t* key_mask, float* logits, int all_logits, void* ws,
+                       size_t ws_bytes, void* layer_tap, void* stream);
+
+/* One greedy decode step for B sequences: embeds ids_in[b] (device int64), runs the decoder at position
+   pos0 + *pos_dev against the cache, writes fp32 logits [B, V] (optional) and ids_out[b] = argmax
+   (optional).  If advance_pos != 0 the device counter *pos_dev is incremented afterwards, so steps can be
+   enqueued back to back (or replayed from a hipGraph) without host round trips. */
+int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
+                           int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
+                           int64_t* ids_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Greedy decode of n_steps tokens, fully enqueued on the stream: ids_out [n_steps, B] (device int64);
+   the first input token is ids_in.  use_graph != 0 captures one step in a hipGraph and replays it. */
+int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
+                           void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
+                           size_t ws_bytes, int use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISUALCLA_HIP_H */

@@ -1,0 +1,329 @@
+"""Per-kernel parity: every C-ABI primitive against the oracle's restatement of the same op (fp32 CPU),
+on seeded inputs.  Integer/index outputs must match exactly; floating point within the tolerance written
+next to each check.  All calls go through libvisualcla_hip.so via ctypes."""
+import ctypes as C
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import visualcla_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from visualcla import _lib
+    _lib.require_device()
+    return _lib
+
+
+def _report(line: str):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _cmp(name, got, ref, atol, rtol=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    worst = (err - bound).max().item()
+    _report(f"{name}: max_abs_err={err.max().item():.3e} ref_absmax={ref.abs().max().item():.3e}")
+    assert worst <= 0, f"{name}: max err {err.max().item():.3e} exceeds atol={atol} rtol={rtol}"
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(5, 128), (257, 1024), (33, 4096), (3, 100)])
+def test_layernorm(lib, dtype, rows, cols):
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = torch.randn(rows, cols, generator=g) * 2 + 0.3
+    gamma, beta = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    xd = x.to(dtype)
+    ref = O.layer_norm(xd.float(), gamma, beta, 1e-5)
+    got = lib.layernorm(xd.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5)
+    # fp32: summation order only; bf16: one output rounding (2^-9 relative)
+    _cmp(f"layernorm[{dtype},{rows}x{cols}]", got, ref, atol=2e-5 if dtype == torch.float32 else 1e-3, rtol=0 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(4, 256), (128, 4096), (7, 512)])
+def test_rmsnorm(lib, dtype, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.5).to(dtype)
+    gamma = 1 + 0.1 * torch.randn(cols, generator=g)
+    ref = O.llama_rmsnorm(x, gamma, 1e-6).float()     # oracle applies HF's rounding order in `dtype`
+    got = lib.rmsnorm(x.to(DEV), gamma.to(DEV), 1e-6)
+    _cmp(f"rmsnorm[{dtype},{rows}x{cols}]", got, ref, atol=2e-5 if dtype == torch.float32 else 1e-3, rtol=0 if dtype == torch.float32 else 8e-3)
+
+
+def test_layernorm_strided_rows(lib):
+    # last-token selection in prefill: rows picked with a stride larger than cols
+    x = torch.randn(6, 4, 256)
+    gamma, beta = torch.randn(256), torch.randn(256)
+    xd = x.to(DEV)
+    view = xd[:, 3, :]                       # stride 1024
+    out = torch.empty(6, 256, device=DEV)
+    lib.check(lib.load().vcla_layernorm(view.data_ptr(), view.stride(0), gamma.to(DEV).data_ptr(), beta.to(DEV).data_ptr(),
+                                        out.data_ptr(), 256, 6, 256, 1e-5, 0, lib.stream_ptr()))
+    _cmp("layernorm[strided]", out, O.layer_norm(x[:, 3, :], gamma, beta, 1e-5), atol=2e-5)
+
+
+# ------------------------------------------------------------------ GEMM
+def _pack(w):
+    from visualcla.weights import _pack_w
+    return _pack_w(w, DEV)
+
+
+def _gemm_ref(a, w, bias, epi, residual):
+    y = a.float() @ w.float().t()
+    if epi == 3:
+        from visualcla.weights import interleave_gate_up  # noqa: F401  (documented layout)
+        n = w.shape[0]
+        yb = y + (bias if bias is not None else 0)
+        blocks = yb.view(y.shape[0], n // 32, 2, 16)
+        y = torch.nn.functional.silu(blocks[:, :, 0]) * blocks[:, :, 1]
+        y = y.reshape(y.shape[0], n // 2)
+    else:
+        if bias is not None:
+            y = y + bias
+        if epi == 1:
+            y = O.quick_gelu(y)
+        elif epi == 2:
+            y = O.gelu_erf(y)
+    if residual is not None:
+        y = y + residual.float()
+    return y
+
+
+GEMM_SHAPES = [
+    # M, N, K
+    (1, 256, 128), (3, 1000, 256), (8, 4096, 512), (16, 128, 64), (130, 200, 192), (257, 384, 128),
+    (514, 1024, 1024), (64, 320, 640),
+]
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "gemv", "gemv32", "f32"])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm(lib, kernel, epi, M, N, K):
+    if kernel.startswith("gemv") and M > 8:
+        pytest.skip("gemv kernel is for M <= 8")
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M * 1000 + N + K + epi)
+    dtype = torch.float32 if kernel in ("f32", "gemv32") else torch.bfloat16
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    ref = _gemm_ref(a, w, bias, epi, res)
+    fk = {"mfma": 1, "gemv": 2, "gemv32": 2, "f32": 3}[kernel]
+    got = lib.gemm(a.to(DEV, dtype), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, dtype), epilogue=epi,
+                   force_kernel=fk)
+    # inputs are exactly representable; products are exact in fp32; only accumulation order differs (+ one bf16
+    # output rounding in bf16 mode)
+    if dtype == torch.float32:
+        _cmp(f"gemm[{kernel},epi{epi},{M}x{N}x{K}]", got, ref, atol=1e-4, rtol=1e-5)
+    else:
+        _cmp(f"gemm[{kernel},epi{epi},{M}x{N}x{K}]", got, ref, atol=2e-3, rtol=8e-3)
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "gemv"])
+def test_gemm_f32_output_and_identity(lib, kernel):
+    """A = I (asymmetric W) catches operand/row-column swaps; fp32 output keeps the full accumulator."""
+    M = 8 if kernel == "gemv" else 192
+    K, N = 192, 333
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    g = torch.Generator().manual_seed(5)
+    w = bf16r(torch.randn(N, K, generator=g))
+    ref = a @ w.t()
+    got = lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, out_f32=True, force_kernel=1 if kernel == "mfma" else 2)
+    assert got.dtype == torch.float32
+    _cmp(f"gemm_identity[{kernel}]", got, ref, atol=0.0)     # exact: a single non-zero product per output
+
+
+def test_gemm_row_remap(lib):
+    # resampler K/V assembly: rows of two GEMMs interleave into one [B, Q+N, 2D] buffer
+    B, Q, Nn, D = 3, 16, 50, 128
+    g = torch.Generator().manual_seed(9)
+    lat, img = bf16r(torch.randn(B * Q, D, generator=g)), bf16r(torch.randn(B * Nn, D, generator=g))
+    w = bf16r(torch.randn(2 * D, D, generator=g) * 0.05)
+    ref = torch.cat([(lat @ w.t()).view(B, Q, 2 * D), (img @ w.t()).view(B, Nn, 2 * D)], dim=1)
+    for dtype, fk in ((torch.bfloat16, 1), (torch.float32, 3)):
+        out = torch.zeros(B * (Q + Nn), 2 * D, dtype=dtype, device=DEV)
+        wp = _pack(w)
+        lib.gemm(lat.to(DEV, dtype), wp, 2 * D, out=out, force_kernel=fk, group_rows=Q, group_stride=Q + Nn, row_offset=0)
+        lib.gemm(img.to(DEV, dtype), wp, 2 * D, out=out, force_kernel=fk, group_rows=Nn, group_stride=Q + Nn, row_offset=Q)
+        _cmp(f"gemm_remap[{dtype}]", out.view(B, Q + Nn, 2 * D), ref, atol=1e-4 if dtype == torch.float32 else 2e-3, rtol=8e-3)
+
+
+def test_gemm_in_place_residual(lib):
+    M, N, K = 200, 256, 128
+    g = torch.Generator().manual_seed(11)
+    a, w, x = bf16r(torch.randn(M, K, generator=g)), bf16r(torch.randn(N, K, generator=g) * 0.05), bf16r(torch.randn(M, N, generator=g))
+    ref = x + a @ w.t()
+    xd = x.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, residual=xd, out=xd, force_kernel=1)
+    _cmp("gemm_inplace_residual", xd, ref, atol=2e-3, rtol=8e-3)
+
+
+def test_gemm_full_size_shapes_vs_torch(lib):
+    """BASELINE-size GEMMs (ViT fc1 at B=8, LLaMA gate/up at M=1024) against torch's own GPU matmul in fp32."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for (M, N, K, epi) in [(8 * 257, 4096, 1024, 1), (1024, 22016, 4096, 3), (1024, 4096, 11008, 0), (130, 49958, 4096, 0)]:
+        a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+        ref = _gemm_ref(a.float(), w.float(), None, epi, None)
+        wp = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16, device=DEV)
+        wp[:N] = w
+        got = lib.gemm(a, wp, N, epilogue=epi, out_f32=True, force_kernel=1)
+        _cmp(f"gemm_full[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=2e-3)
+
+
+def test_gemm_error_conventions(lib):
+    a = torch.zeros(4, 100, dtype=torch.bfloat16, device=DEV)        # K not a multiple of 64
+    w = torch.zeros(128, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        lib.gemm(a, w, 128)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, scale, causal, key_mask):
+    B, H, Tq, D = q.shape
+    Tk = k.shape[2]
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if causal:
+        qpos = torch.arange(Tq)[:, None] + (Tk - Tq)
+        s = s.masked_fill(torch.arange(Tk)[None, :] > qpos, float("-inf"))
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, None, :Tk] == 0, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ v.float()).transpose(1, 2).reshape(B, Tq, H * D)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,D,causal", [
+    (2, 4, 17, 17, 32, False), (2, 3, 257, 257, 64, False), (1, 2, 64, 321, 64, False),
+    (2, 4, 48, 48, 128, True), (2, 2, 1, 77, 128, True), (1, 2, 5, 130, 64, True), (1, 1, 130, 130, 128, True),
+])
+def test_attention_generic(lib, dtype, B, H, Tq, Tk, D, causal):
+    g = torch.Generator().manual_seed(B + H + Tq + Tk + D)
+    q, k, v = (bf16r(torch.randn(B, H, T, D, generator=g)) for T in (Tq, Tk, Tk))
+    ref = _attn_ref(q, k, v, 1 / math.sqrt(D), causal, None)
+    got = lib.attention(q.to(DEV, dtype), k.to(DEV, dtype), v.to(DEV, dtype), 1 / math.sqrt(D), causal=causal, force_kernel=1)
+    # bf16: probabilities and the output are rounded to bf16 (as HF does), |v| ~ 1
+    _cmp(f"attn_generic[{dtype},B{B}H{H}Tq{Tq}Tk{Tk}D{D}c{int(causal)}]", got, ref, atol=2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_attention_key_mask_and_strides(lib):
+    # fused-qkv strides (ViT layout) + left-padding mask
+    B, H, T, D = 2, 4, 40, 64
+    g = torch.Generator().manual_seed(1)
+    qkv = bf16r(torch.randn(B, T, 3 * H * D, generator=g))
+    km = torch.ones(B, T, dtype=torch.int32)
+    km[1, :7] = 0
+    q, k, v = (qkv[..., i * H * D:(i + 1) * H * D].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    ref = _attn_ref(q, k, v, 0.125, True, km)
+    qd = qkv.to(DEV)
+    qv, kv, vv = (qd[..., i * H * D:(i + 1) * H * D].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    got = lib.attention(qv, kv, vv, 0.125, causal=True, key_mask=km.to(DEV), force_kernel=1)
+    # rows whose every visible key is masked are don't-care (HF gives them uniform garbage); compare the rest
+    valid = torch.ones(B, T, dtype=torch.bool)
+    valid[1, :7] = False
+    _cmp("attn_mask_strided", got[valid.to(DEV)], ref[valid], atol=2e-5)
+
+
+# ------------------------------------------------------------------ embed / rope / argmax / im2col
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_splice(lib, dtype):
+    B, T, Q, D, V = 3, 20, 5, 64, 97
+    g = torch.Generator().manual_seed(2)
+    table = bf16r(torch.randn(V, D, generator=g))
+    img = bf16r(torch.randn(B, Q, D, generator=g))
+    ids = torch.randint(0, V, (B, T), generator=g)
+    pos = torch.tensor([3, -1, 14], dtype=torch.int32)
+    ref = table[ids].clone()
+    for b in range(B):
+        if pos[b] >= 0:
+            ref[b, pos[b] + 1:pos[b] + 1 + Q] = img[b]
+    out = torch.empty(B, T, D, dtype=dtype, device=DEV)
+    L = lib.load()
+    lib.check(L.vcla_embed_splice(ids.to(DEV).data_ptr(), table.to(DEV, torch.bfloat16).data_ptr(), img.to(DEV, dtype).data_ptr(),
+                                  pos.to(DEV).data_ptr(), out.data_ptr(), B, T, Q, D, V, lib.dtype_code(dtype), lib.stream_ptr()))
+    _cmp(f"embed_splice[{dtype}]", out, ref, atol=0.0)       # pure data movement: bit exact
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_kv_append(lib, dtype):
+    B, T, H, d, ctx, pos0 = 2, 5, 3, 64, 16, 4
+    g = torch.Generator().manual_seed(4)
+    qkv = bf16r(torch.randn(B, T, 3, H, d, generator=g))
+    from visualcla.weights import rope_tables
+    cos, sin = rope_tables(32, d, 10000.0)
+    positions = torch.arange(pos0, pos0 + T)
+    c, s = O.llama_rope_tables(positions, d, 10000.0, torch.float32)
+    if dtype == torch.bfloat16:
+        c, s = bf16r(c), bf16r(s)
+    qr = O.apply_rope(qkv[:, :, 0].transpose(1, 2), c, s)          # [B,H,T,d]
+    kr = O.apply_rope(qkv[:, :, 1].transpose(1, 2), c, s)
+    buf = qkv.reshape(B * T, 3 * H * d).to(DEV, dtype).contiguous()
+    kc = torch.zeros(B, H, ctx, d, dtype=dtype, device=DEV)
+    vc = torch.zeros(B, H, ctx, d, dtype=dtype, device=DEV)
+    pos_dev = torch.tensor([1], dtype=torch.int32, device=DEV)
+    L = lib.load()
+    lib.check(L.vcla_rope_kv_append(buf.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.to(DEV).data_ptr(), sin.to(DEV).data_ptr(),
+                                    B, T, H, d, ctx, pos0 - 1, pos_dev.data_ptr(), lib.dtype_code(dtype), lib.stream_ptr()))
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    _cmp(f"rope_q[{dtype}]", buf.view(B, T, 3, H, d)[:, :, 0].transpose(1, 2), qr, atol=tol)
+    _cmp(f"rope_k_cache[{dtype}]", kc[:, :, pos0:pos0 + T], kr, atol=tol)
+    _cmp(f"v_cache[{dtype}]", vc[:, :, pos0:pos0 + T], qkv[:, :, 2].transpose(1, 2), atol=0.0)
+    assert float(kc[:, :, :pos0].abs().max()) == 0.0 and float(kc[:, :, pos0 + T:].abs().max()) == 0.0
+
+
+def test_argmax_first_max(lib):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(5, 49958, generator=g)
+    x[2, 100] = x[2, 40000] = 99.0          # tie -> lowest index
+    x[3, -1] = 123.0
+    got = lib.argmax(x.to(DEV)).cpu()
+    assert torch.equal(got, x.argmax(dim=-1)), (got, x.argmax(dim=-1))
+    assert got[2] == 100 and got[3] == 49957
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_embed_pipeline(lib, dtype):
+    """im2col + GEMM + class/pos assembly + pre-LN == oracle.clip_embeddings."""
+    cfg = O.cfg_small().vision
+    W = O.make_weights(O.cfg_small(), seed=0)
+    px = bf16r(torch.randn(2, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(8)))
+    ref = O.clip_embeddings(px, W, cfg)
+    p = "vision_model.vision_model."
+    D, P = cfg.hidden_size, cfg.patch_size
+    kreal, kpad = 3 * P * P, (3 * P * P + 63) // 64 * 64
+    L = lib.load()
+    np_ = cfg.num_patches
+    patches = torch.empty(2 * np_, kpad, dtype=dtype, device=DEV)
+    lib.check(L.vcla_im2col(px.to(DEV, dtype).contiguous().data_ptr(), patches.data_ptr(), 2, 3, cfg.image_size, cfg.image_size,
+                            P, kpad, lib.dtype_code(dtype), lib.stream_ptr()))
+    wp = torch.nn.functional.pad(W[p + "embeddings.patch_embedding.weight"].reshape(D, kreal), (0, kpad - kreal))
+    pe = lib.gemm(patches, _pack(wp), D)
+    out = torch.empty(2 * (np_ + 1), D, dtype=dtype, device=DEV)
+    f = lambda n: W[p + n].float().to(DEV).contiguous()
+    cls, pos, gm, bt = f("embeddings.class_embedding"), f("embeddings.position_embedding.weight"), f("pre_layrnorm.weight"), f("pre_layrnorm.bias")
+    lib.check(L.vcla_vit_assemble(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), gm.data_ptr(), bt.data_ptr(), out.data_ptr(),
+                                  2, np_, D, cfg.layer_norm_eps, lib.dtype_code(dtype), lib.stream_ptr()))
+    _cmp(f"patch_embed[{dtype}]", out.view(2, np_ + 1, D), ref, atol=1e-4 if dtype == torch.float32 else 6e-2)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One gpurun call = the whole measurement loop: env info, per-kernel parity, model parity, bench, rocprof stats.
+# Usage (on the GPU box, from the repo root): bash tools/gpu_check.sh [quick|full]
+mode=${1:-full}
+mkdir -p gpurun_out
+exec > >(tee gpurun_out/gpu_check.log) 2>&1
+echo "== host"; nproc; free -g | head -2; rocminfo | grep -E "Marketing|gfx|Compute Unit" | head -8
+python -c "import torch;print(torch.__version__, torch.cuda.device_count(), torch.cuda.get_device_name(0))"
+rm -f gpurun_out/parity_report.txt
+echo "== kernel parity"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
+echo "== model parity"; timeout 1200 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
+if [ "$mode" != "quick" ]; then
+  echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
+  echo "== bench"; timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 | tee gpurun_out/bench.log
+  echo "== rocprof"; cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3
+  cd $GRAFT_REPO_ROOT; ls gpurun_out/prof* 2>/dev/null | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
+fi
+echo "== done"

@@ -1,0 +1,179 @@
+// embed.hip -- data-movement kernels either side of the GEMMs: patch gather (im2col), token
+// embedding gather + image splice, RoPE + KV-cache append, greedy argmax.  All HBM-bound.
+#include "vcla_common.h"
+
+// ------------------------------------------------------------------ im2col for the patch conv
+// out[(b*gh + py)*gw + px][c*P*P + ky*P + kx] = pix[b][c][py*P+ky][px*P+kx]; columns >= C*P*P are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ pix, T* __restrict__ out, int C, int H,
+                                                     int W, int P, int k_pad) {
+    const int gw = W / P, gh = H / P;
+    const int64_t prow = blockIdx.x;  // patch row index
+    const int b = (int)(prow / (gh * gw));
+    const int py = (int)((prow / gw) % gh), px = (int)(prow % gw);
+    const int kreal = C * P * P;
+    T* o = out + prow * k_pad;
+    for (int k = threadIdx.x; k < k_pad; k += 256) {
+        if (k < kreal) {
+            const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
+            o[k] = pix[(((int64_t)b * C + c) * H + (py * P + ky)) * W + (px * P + kx)];
+        } else {
+            Act<T>::st(o + k, 0.f);
+        }
+    }
+}
+
+extern "C" int vcla_im2col(const void* pixels, void* patches, int B, int C, int H, int W, int P, int k_pad,
+                           int dtype, void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "im2col: bad dtype %d", dtype);
+    VCLA_REQUIRE(B >= 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && k_pad >= C * P * P, VCLA_ERR_BAD_SHAPE,
+                 "im2col: B=%d C=%d H=%d W=%d P=%d k_pad=%d", B, C, H, W, P, k_pad);
+    VCLA_REQUIRE(pixels && patches, VCLA_ERR_BAD_ARG, "im2col: null pointer");
+    const int64_t rows = (int64_t)B * (H / P) * (W / P);
+    if (rows == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VCLA_F32)
+        im2col_kernel<float><<<(unsigned)rows, 256, 0, s>>>((const float*)pixels, (float*)patches, C, H, W, P, k_pad);
+    else
+        im2col_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>((const bf16_t*)pixels, (bf16_t*)patches, C, H, W, P, k_pad);
+    VCLA_CHECK_LAUNCH("im2col_kernel");
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ embedding gather + image splice
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids,
+                                                           const bf16_t* __restrict__ table,
+                                                           const T* __restrict__ img,
+                                                           const int32_t* __restrict__ img_pos, T* __restrict__ out,
+                                                           int T_, int Q, int D, int V) {
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / T_), t = (int)(row % T_);
+    T* o = out + row * D;
+    const int p0 = (img && img_pos) ? img_pos[b] : -1;
+    if (p0 >= 0 && t > p0 && t <= p0 + Q) {
+        const T* src = img + ((int64_t)b * Q + (t - p0 - 1)) * D;
+        for (int c = threadIdx.x; c < D; c += 256) o[c] = src[c];
+    } else {
+        int64_t id = ids[row];
+        if (id < 0 || id >= V) id = 0;  // out-of-range ids are rejected on the host; stay in bounds here
+        const bf16_t* src = table + id * D;
+        for (int c = threadIdx.x; c < D; c += 256) Act<T>::st(o + c, bf2f(src[c]));
+    }
+}
+
+extern "C" int vcla_embed_splice(const int64_t* ids, const void* table, const void* image_embeds,
+                                 const int32_t* img_pos, void* out, int B, int T, int Q, int D, int V, int dtype,
+                                 void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "embed_splice: bad dtype %d", dtype);
+    VCLA_REQUIRE(B >= 0 && T >= 0 && D > 0 && V > 0 && Q >= 0, VCLA_ERR_BAD_SHAPE, "embed_splice: B=%d T=%d Q=%d D=%d V=%d",
+                 B, T, Q, D, V);
+    VCLA_REQUIRE(ids && table && out, VCLA_ERR_BAD_ARG, "embed_splice: null pointer");
+    const int64_t rows = (int64_t)B * T;
+    if (rows == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VCLA_F32)
+        embed_splice_kernel<float><<<(unsigned)rows, 256, 0, s>>>(ids, (const bf16_t*)table, (const float*)image_embeds,
+                                                                  img_pos, (float*)out, T, Q, D, V);
+    else
+        embed_splice_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>(ids, (const bf16_t*)table,
+                                                                   (const bf16_t*)image_embeds, img_pos, (bf16_t*)out,
+                                                                   T, Q, D, V);
+    VCLA_CHECK_LAUNCH("embed_splice_kernel");
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ RoPE (rotate-half form) + KV append
+// qkv row r = b*T + t : [ q (H*d) | k (H*d) | v (H*d) ].  One workgroup per row; thread handles (h, i<d/2) pairs.
+// q' = q*cos + rot(q)*sin with rot(x) = cat(-x[d/2:], x[:d/2]); cos/sin are rounded to the activation dtype
+// first (HF casts the fp32 tables to x.dtype, hf:llama/modeling_llama.py:127).
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                      const float* __restrict__ cos_tab,
+                                                      const float* __restrict__ sin_tab, int T_, int H, int d,
+                                                      int ctx_max, int pos0, const int32_t* __restrict__ pos_dev) {
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / T_), t = (int)(row % T_);
+    const int pos = pos0 + (pos_dev ? *pos_dev : 0) + t;
+    const int half = d / 2;
+    const int HD = H * d;
+    T* q = qkv + row * 3 * HD;
+    T* k = q + HD;
+    const T* v = k + HD;
+    const float* cs = cos_tab + (int64_t)pos * half;
+    const float* sn = sin_tab + (int64_t)pos * half;
+    for (int idx = threadIdx.x; idx < H * half; idx += 256) {
+        const int h = idx / half, i = idx % half;
+        const float c = Act<T>::rnd(cs[i]), s = Act<T>::rnd(sn[i]);
+        const int o = h * d + i;
+        const float q0 = Act<T>::ld(q + o), q1 = Act<T>::ld(q + o + half);
+        Act<T>::st(q + o, q0 * c - q1 * s);
+        Act<T>::st(q + o + half, q1 * c + q0 * s);
+        const float k0 = Act<T>::ld(k + o), k1 = Act<T>::ld(k + o + half);
+        T* kd = kc + (((int64_t)b * H + h) * ctx_max + pos) * d + i;
+        Act<T>::st(kd, k0 * c - k1 * s);
+        Act<T>::st(kd + half, k1 * c + k0 * s);
+    }
+    for (int idx = threadIdx.x; idx < HD; idx += 256) {
+        const int h = idx / d, i = idx % d;
+        vc[(((int64_t)b * H + h) * ctx_max + pos) * d + i] = v[idx];
+    }
+}
+
+extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
+                                   const float* sin_tab, int B, int T, int H, int d, int ctx_max, int pos0,
+                                   const int32_t* pos_dev, int dtype, void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "rope_kv_append: bad dtype %d", dtype);
+    VCLA_REQUIRE(B >= 0 && T >= 0 && H > 0 && d > 0 && d % 2 == 0 && ctx_max > 0 && pos0 >= 0, VCLA_ERR_BAD_SHAPE,
+                 "rope_kv_append: B=%d T=%d H=%d d=%d ctx_max=%d pos0=%d", B, T, H, d, ctx_max, pos0);
+    VCLA_REQUIRE(pos_dev || pos0 + T <= ctx_max, VCLA_ERR_BAD_SHAPE, "rope_kv_append: pos0 %d + T %d > ctx_max %d",
+                 pos0, T, ctx_max);
+    VCLA_REQUIRE(qkv && k_cache && v_cache && cos_tab && sin_tab, VCLA_ERR_BAD_ARG, "rope_kv_append: null pointer");
+    const int64_t rows = (int64_t)B * T;
+    if (rows == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VCLA_F32)
+        rope_kv_kernel<float><<<(unsigned)rows, 256, 0, s>>>((float*)qkv, (float*)k_cache, (float*)v_cache, cos_tab,
+                                                             sin_tab, T, H, d, ctx_max, pos0, pos_dev);
+    else
+        rope_kv_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                                                              cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
+    VCLA_CHECK_LAUNCH("rope_kv_kernel");
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ argmax (first maximum, like torch.argmax)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     int64_t* __restrict__ out, int V) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float* x = logits + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += 256) {
+        const float v = x[j];
+        if (v > best || (v == best && j < bi)) { best = v; bi = j; }   // NaNs never win; index ties -> lowest
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        out[blockIdx.x] = (bi == 0x7fffffff) ? 0 : bi;
+    }
+}
+
+extern "C" int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream) {
+    VCLA_REQUIRE(B >= 0 && V > 0 && ld >= V, VCLA_ERR_BAD_SHAPE, "argmax: B=%d V=%d ld=%lld", B, V, (long long)ld);
+    VCLA_REQUIRE(logits && ids_out, VCLA_ERR_BAD_ARG, "argmax: null pointer");
+    if (B == 0) return VCLA_OK;
+    argmax_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, ids_out, V);
+    VCLA_CHECK_LAUNCH("argmax_kernel");
+    return VCLA_OK;
+}

@@ -1,0 +1,576 @@
+// engine.hip -- model context + launch orchestration (host side of libvisualcla_hip.so).
+//
+// The three macro entry points issue every kernel of their stage from C++ on the caller's stream, so a
+// forward / decode step costs ONE Python->C transition instead of ~200:
+//   vcla_vision_forward     ViT-L/14 -> post-LN(all tokens) -> Resampler -> projection
+//   vcla_llama_prefill      LLaMA decoder over the spliced prompt embeds, fills the KV cache
+//   vcla_llama_decode_step  one greedy step against the cache (position / context length live in device memory
+//                           so the identical launch sequence can be replayed from a hipGraph)
+// Memory: nothing is allocated here.  Weights are caller-owned device tensors registered by name; activations
+// live in a caller-provided workspace carved by a bump allocator; the KV cache is caller-owned.
+#include "vcla_common.h"
+
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ------------------------------------------------------------------ errors / version
+static thread_local char g_err[1024] = "";
+
+void vcla_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int vcla_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* vcla_last_error(void) { return g_err; }
+extern "C" int vcla_version(void) { return VCLA_ABI_VERSION; }
+
+extern "C" int vcla_device_check(void) {
+    int dev = 0;
+    VCLA_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    VCLA_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0)
+        return vcla_fail(VCLA_ERR_UNSUPPORTED_ARCH, "device %d is %s; this library is built for gfx950 only", dev, p.gcnArchName);
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ tiny helper kernels
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_per) {
+    // dst[b, :] = src[:] for b = blockIdx.y
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_per) dst[(int64_t)blockIdx.y * n_per + i] = src[i];
+}
+
+__global__ void advance_pos_kernel(int32_t* pos) { *pos += 1; }
+
+// ids_out[(*pos_dev - step_base) * B + b] = cur[b]
+__global__ void record_ids_kernel(const int64_t* __restrict__ cur, int64_t* __restrict__ ids_out,
+                                  const int32_t* __restrict__ pos_dev, int step_base, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) ids_out[(int64_t)(*pos_dev - step_base) * B + b] = cur[b];
+}
+
+// ------------------------------------------------------------------ context
+struct TensorRef {
+    const void* ptr;
+    size_t nbytes;
+};
+
+struct VitLayer {
+    const float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *b1, *b2;
+    const void *wqkv, *wo, *w1, *w2;
+};
+struct ResLayer {
+    const float *bq, *bkv, *bo, *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
+    const void *wq, *wkv, *wo, *w1, *w2;
+};
+struct LlamaLayer {
+    const float *ln1g, *ln2g;
+    const void *wqkv, *wo, *wgu, *wd;
+};
+
+struct vcla_ctx {
+    vcla_model_cfg c;
+    std::unordered_map<std::string, TensorRef> tensors;
+    bool finalized = false;
+    // resolved
+    const void* vit_patch_w = nullptr;
+    const float *vit_cls = nullptr, *vit_pos = nullptr, *vit_pre_g = nullptr, *vit_pre_b = nullptr, *vit_post_g = nullptr,
+                *vit_post_b = nullptr;
+    std::vector<VitLayer> vit;
+    const void* res_query = nullptr;
+    std::vector<ResLayer> res;
+    const void* proj_w = nullptr;
+    const float* proj_b = nullptr;
+    const void* embed = nullptr;
+    std::vector<LlamaLayer> llama;
+    const float* norm_g = nullptr;
+    const void* lm_head = nullptr;
+    const float *rope_cos = nullptr, *rope_sin = nullptr;
+    int k_pad = 0;  // padded im2col width
+    // cached decode graph
+    hipGraphExec_t graph_exec = nullptr;
+    struct {
+        const void *ids, *kv, *mask, *ws, *out;
+        int B, pos0, ctx_max, step_base;
+        const void* pos_dev;
+    } graph_key = {};
+};
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t esz(const vcla_ctx* c) { return vcla_dtype_size(c->c.act_dtype); }
+
+extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
+    VCLA_REQUIRE(cfg && out, VCLA_ERR_BAD_ARG, "ctx_create: null pointer");
+    const vcla_model_cfg& c = *cfg;
+    VCLA_REQUIRE(c.act_dtype == VCLA_F32 || c.act_dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "ctx_create: bad act_dtype %d", c.act_dtype);
+    auto head_ok = [](int hidden, int heads) {
+        if (heads <= 0 || hidden % heads) return false;
+        const int d = hidden / heads;
+        return d == 32 || d == 64 || d == 128;
+    };
+    VCLA_REQUIRE(head_ok(c.v_hidden, c.v_heads) && head_ok(c.r_hidden, c.r_heads) && head_ok(c.t_hidden, c.t_heads),
+                 VCLA_ERR_BAD_SHAPE, "ctx_create: head dims must be 32, 64 or 128 (vision %d/%d, resampler %d/%d, text %d/%d)",
+                 c.v_hidden, c.v_heads, c.r_hidden, c.r_heads, c.t_hidden, c.t_heads);
+    VCLA_REQUIRE(c.v_hidden % 64 == 0 && c.v_inter % 64 == 0 && c.r_hidden % 64 == 0 && c.r_inter % 64 == 0 &&
+                     c.t_hidden % 64 == 0 && c.t_inter % 64 == 0, VCLA_ERR_BAD_SHAPE,
+                 "ctx_create: hidden / intermediate sizes must be multiples of 64");
+    VCLA_REQUIRE(c.t_inter % 16 == 0, VCLA_ERR_BAD_SHAPE, "ctx_create: t_inter must be a multiple of 16 (SwiGLU packing)");
+    VCLA_REQUIRE(c.r_hidden == c.v_hidden, VCLA_ERR_BAD_SHAPE,
+                 "ctx_create: resampler hidden (%d) must equal vision hidden (%d): latents are concatenated with image tokens",
+                 c.r_hidden, c.v_hidden);
+    VCLA_REQUIRE(c.v_patch > 0 && c.v_image % c.v_patch == 0 && c.v_layers > 0 && c.r_layers > 0 && c.t_layers > 0 &&
+                     c.r_queries > 0 && c.t_vocab > 0 && c.t_max_pos > 0 && c.v_channels > 0,
+                 VCLA_ERR_BAD_SHAPE, "ctx_create: bad geometry");
+    vcla_ctx* x = new (std::nothrow) vcla_ctx();
+    VCLA_REQUIRE(x, VCLA_ERR_BAD_ARG, "ctx_create: out of host memory");
+    x->c = c;
+    x->k_pad = pad_to(c.v_channels * c.v_patch * c.v_patch, 64);
+    *out = x;
+    return VCLA_OK;
+}
+
+extern "C" void vcla_ctx_destroy(vcla_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    delete ctx;
+}
+
+extern "C" int vcla_ctx_set_tensor(vcla_ctx* ctx, const char* name, const void* ptr, size_t nbytes) {
+    VCLA_REQUIRE(ctx && name && ptr, VCLA_ERR_BAD_ARG, "ctx_set_tensor: null pointer");
+    VCLA_REQUIRE(vcla_aligned(ptr, 16), VCLA_ERR_BAD_ARG, "ctx_set_tensor: %s is not 16-byte aligned", name);
+    ctx->tensors[name] = TensorRef{ptr, nbytes};
+    ctx->finalized = false;
+    return VCLA_OK;
+}
+
+static int get_tensor(vcla_ctx* ctx, const std::string& name, size_t want_bytes, const void** out) {
+    auto it = ctx->tensors.find(name);
+    if (it == ctx->tensors.end()) return vcla_fail(VCLA_ERR_MISSING_TENSOR, "tensor '%s' was not registered", name.c_str());
+    if (it->second.nbytes != want_bytes)
+        return vcla_fail(VCLA_ERR_BAD_SHAPE, "tensor '%s' has %zu bytes, expected %zu", name.c_str(), it->second.nbytes, want_bytes);
+    *out = it->second.ptr;
+    return VCLA_OK;
+}
+
+#define GET_W(dst, name, rows, cols)                                                                       \
+    do {                                                                                                   \
+        const void* _p;                                                                                    \
+        int _rc = get_tensor(ctx, name, (size_t)pad_to(rows, 128) * (size_t)(cols) * 2, &_p);               \
+        if (_rc) return _rc;                                                                               \
+        dst = _p;                                                                                          \
+    } while (0)
+#define GET_F(dst, name, n)                                                         \
+    do {                                                                            \
+        const void* _p;                                                             \
+        int _rc = get_tensor(ctx, name, (size_t)(n) * 4, &_p);                      \
+        if (_rc) return _rc;                                                        \
+        dst = (const float*)_p;                                                     \
+    } while (0)
+
+extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
+    VCLA_REQUIRE(ctx, VCLA_ERR_BAD_ARG, "ctx_finalize: null ctx");
+    const vcla_model_cfg& c = ctx->c;
+    const int np = (c.v_image / c.v_patch) * (c.v_image / c.v_patch), N = np + 1;
+    GET_W(ctx->vit_patch_w, "vit.patch_w", c.v_hidden, ctx->k_pad);
+    GET_F(ctx->vit_cls, "vit.cls", c.v_hidden);
+    GET_F(ctx->vit_pos, "vit.pos", (size_t)N * c.v_hidden);
+    GET_F(ctx->vit_pre_g, "vit.pre_ln.g", c.v_hidden);
+    GET_F(ctx->vit_pre_b, "vit.pre_ln.b", c.v_hidden);
+    GET_F(ctx->vit_post_g, "vit.post_ln.g", c.v_hidden);
+    GET_F(ctx->vit_post_b, "vit.post_ln.b", c.v_hidden);
+    ctx->vit.resize(c.v_layers);
+    for (int i = 0; i < c.v_layers; ++i) {
+        const std::string p = "vit.l" + std::to_string(i) + ".";
+        VitLayer& L = ctx->vit[i];
+        GET_F(L.ln1g, p + "ln1.g", c.v_hidden); GET_F(L.ln1b, p + "ln1.b", c.v_hidden);
+        GET_W(L.wqkv, p + "wqkv", 3 * c.v_hidden, c.v_hidden); GET_F(L.bqkv, p + "bqkv", 3 * c.v_hidden);
+        GET_W(L.wo, p + "wo", c.v_hidden, c.v_hidden); GET_F(L.bo, p + "bo", c.v_hidden);
+        GET_F(L.ln2g, p + "ln2.g", c.v_hidden); GET_F(L.ln2b, p + "ln2.b", c.v_hidden);
+        GET_W(L.w1, p + "w1", c.v_inter, c.v_hidden); GET_F(L.b1, p + "b1", c.v_inter);
+        GET_W(L.w2, p + "w2", c.v_hidden, c.v_inter); GET_F(L.b2, p + "b2", c.v_hidden);
+    }
+    {
+        const void* q;
+        int rc = get_tensor(ctx, "res.query", (size_t)c.r_queries * c.r_hidden * esz(ctx), &q);
+        if (rc) return rc;
+        ctx->res_query = q;
+    }
+    ctx->res.resize(c.r_layers);
+    for (int i = 0; i < c.r_layers; ++i) {
+        const std::string p = "res.l" + std::to_string(i) + ".";
+        ResLayer& L = ctx->res[i];
+        GET_W(L.wq, p + "wq", c.r_hidden, c.r_hidden); GET_F(L.bq, p + "bq", c.r_hidden);
+        GET_W(L.wkv, p + "wkv", 2 * c.r_hidden, c.r_hidden); GET_F(L.bkv, p + "bkv", 2 * c.r_hidden);
+        GET_W(L.wo, p + "wo", c.r_hidden, c.r_hidden); GET_F(L.bo, p + "bo", c.r_hidden);
+        GET_F(L.ln1g, p + "ln1.g", c.r_hidden); GET_F(L.ln1b, p + "ln1.b", c.r_hidden);
+        GET_W(L.w1, p + "w1", c.r_inter, c.r_hidden); GET_F(L.b1, p + "b1", c.r_inter);
+        GET_W(L.w2, p + "w2", c.r_hidden, c.r_inter); GET_F(L.b2, p + "b2", c.r_hidden);
+        GET_F(L.ln2g, p + "ln2.g", c.r_hidden); GET_F(L.ln2b, p + "ln2.b", c.r_hidden);
+    }
+    GET_W(ctx->proj_w, "proj.w", c.t_hidden, c.r_hidden);
+    GET_F(ctx->proj_b, "proj.b", c.t_hidden);
+    {
+        const void* e;
+        int rc = get_tensor(ctx, "llama.embed", (size_t)c.t_vocab * c.t_hidden * 2, &e);
+        if (rc) return rc;
+        ctx->embed = e;
+    }
+    ctx->llama.resize(c.t_layers);
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "llama.l" + std::to_string(i) + ".";
+        LlamaLayer& L = ctx->llama[i];
+        GET_F(L.ln1g, p + "ln1.g", c.t_hidden); GET_F(L.ln2g, p + "ln2.g", c.t_hidden);
+        GET_W(L.wqkv, p + "wqkv", 3 * c.t_hidden, c.t_hidden);
+        GET_W(L.wo, p + "wo", c.t_hidden, c.t_hidden);
+        GET_W(L.wgu, p + "wgu", 2 * c.t_inter, c.t_hidden);
+        GET_W(L.wd, p + "wd", c.t_hidden, c.t_inter);
+    }
+    GET_F(ctx->norm_g, "llama.norm.g", c.t_hidden);
+    GET_W(ctx->lm_head, "llama.lm_head", c.t_vocab, c.t_hidden);
+    const int d = c.t_hidden / c.t_heads;
+    GET_F(ctx->rope_cos, "llama.rope_cos", (size_t)c.t_max_pos * (d / 2));
+    GET_F(ctx->rope_sin, "llama.rope_sin", (size_t)c.t_max_pos * (d / 2));
+    ctx->finalized = true;
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+struct Bump {
+    char* base;
+    size_t off, cap;
+    void* take(size_t bytes) {
+        const size_t o = (off + 255) & ~(size_t)255;
+        off = o + bytes;
+        return base ? base + o : nullptr;
+    }
+};
+
+struct VisionWs {
+    void *patches, *patch_emb, *x, *h, *qkv, *mlp;          // ViT
+    void *lat, *q, *kv, *ao, *t, *h2, *ffn;                 // resampler
+};
+static size_t carve_vision(const vcla_ctx* ctx, int B, char* base, VisionWs* w) {
+    const vcla_model_cfg& c = ctx->c;
+    const size_t e = esz(ctx);
+    const size_t np = (size_t)(c.v_image / c.v_patch) * (c.v_image / c.v_patch), N = np + 1, Q = c.r_queries;
+    Bump b{base, 0, 0};
+    VisionWs t;
+    t.patches = b.take(B * np * ctx->k_pad * e);
+    t.patch_emb = b.take(B * np * c.v_hidden * e);
+    t.x = b.take(B * N * c.v_hidden * e);
+    t.h = b.take(B * N * c.v_hidden * e);
+    t.qkv = b.take(B * N * 3 * c.v_hidden * e);
+    t.mlp = b.take(B * N * c.v_inter * e);
+    t.lat = b.take(B * Q * c.r_hidden * e);
+    t.q = b.take(B * Q * c.r_hidden * e);
+    t.kv = b.take(B * (Q + N) * 2 * c.r_hidden * e);
+    t.ao = b.take(B * Q * c.r_hidden * e);
+    t.t = b.take(B * Q * c.r_hidden * e);
+    t.h2 = b.take(B * Q * c.r_hidden * e);
+    t.ffn = b.take(B * Q * c.r_inter * e);
+    if (w) *w = t;
+    return b.off + 256;
+}
+extern "C" size_t vcla_vision_workspace_bytes(const vcla_ctx* ctx, int B) {
+    if (!ctx || B <= 0) return 0;
+    return carve_vision(ctx, B, nullptr, nullptr);
+}
+
+struct LlamaWs {
+    void *x, *h, *qkv, *ao, *act, *hl;
+    float* logits;
+    int64_t* ids;
+};
+static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
+    const vcla_model_cfg& c = ctx->c;
+    const size_t e = esz(ctx);
+    const size_t M = (size_t)B * T;
+    Bump b{base, 0, 0};
+    LlamaWs t;
+    t.x = b.take(M * c.t_hidden * e);
+    t.h = b.take(M * c.t_hidden * e);
+    t.qkv = b.take(M * 3 * c.t_hidden * e);
+    t.ao = b.take(M * c.t_hidden * e);
+    t.act = b.take(M * c.t_inter * e);
+    t.hl = b.take((size_t)B * c.t_hidden * e);
+    t.logits = (float*)b.take((size_t)B * c.t_vocab * 4);
+    t.ids = (int64_t*)b.take((size_t)B * 8);
+    if (w) *w = t;
+    return b.off + 256;
+}
+extern "C" size_t vcla_llama_workspace_bytes(const vcla_ctx* ctx, int B, int T) {
+    if (!ctx || B <= 0 || T <= 0) return 0;
+    return carve_llama(ctx, B, T, nullptr, nullptr);
+}
+extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
+    if (!ctx || B <= 0 || ctx_max <= 0) return 0;
+    return (size_t)ctx->c.t_layers * 2 * B * ctx->c.t_hidden * (size_t)ctx_max * esz(ctx);
+}
+
+// ------------------------------------------------------------------ small wrappers
+static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
+                const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
+                int grp_rows = 0, int grp_stride = 0, int row_off = 0) {
+    vcla_gemm_args a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32;
+    a.c_group_rows = grp_rows; a.c_group_stride = grp_stride; a.c_row_offset = row_off;
+    a.force_kernel = 0;
+    return vcla_gemm(&a, ctx->c.act_dtype, s);
+}
+
+#define RUN(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+static int tap_copy(void* tap, size_t index, const void* src, size_t bytes, hipStream_t s) {
+    if (!tap) return VCLA_OK;
+    VCLA_CHECK_HIP(hipMemcpyAsync((char*)tap + index * bytes, src, bytes, hipMemcpyDeviceToDevice, s));
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ vision: ViT + post-LN + resampler + projection
+extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws,
+                                   size_t ws_bytes, void* vit_tap, void* res_tap, void* stream) {
+    VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "vision_forward: context not finalized");
+    VCLA_REQUIRE(pixel_values && image_embeds && ws, VCLA_ERR_BAD_ARG, "vision_forward: null pointer");
+    VCLA_REQUIRE(B > 0, VCLA_ERR_BAD_SHAPE, "vision_forward: B=%d", B);
+    VCLA_REQUIRE(ws_bytes >= vcla_vision_workspace_bytes(ctx, B), VCLA_ERR_WORKSPACE, "vision_forward: workspace %zu < %zu bytes",
+                 ws_bytes, vcla_vision_workspace_bytes(ctx, B));
+    const vcla_model_cfg& c = ctx->c;
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = c.act_dtype;
+    const size_t e = esz(ctx);
+    const int g = c.v_image / c.v_patch, np = g * g, N = np + 1, D = c.v_hidden, H = c.v_heads, d = D / H;
+    VisionWs w;
+    carve_vision(ctx, B, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    const int M = B * N;
+
+    // patch embedding: im2col -> GEMM (no bias) -> class/position embedding + pre-LN
+    RUN(vcla_im2col(pixel_values, w.patches, B, c.v_channels, c.v_image, c.v_image, c.v_patch, ctx->k_pad, dt, s));
+    RUN(gemm(ctx, s, w.patches, ctx->k_pad, ctx->vit_patch_w, nullptr, nullptr, 0, w.patch_emb, D, B * np, D, ctx->k_pad, VCLA_EPI_NONE));
+    RUN(vcla_vit_assemble(w.patch_emb, ctx->vit_cls, ctx->vit_pos, ctx->vit_pre_g, ctx->vit_pre_b, w.x, B, np, D, c.v_eps, dt, s));
+
+    for (int l = 0; l < c.v_layers; ++l) {
+        const VitLayer& L = ctx->vit[l];
+        RUN(vcla_layernorm(w.x, D, L.ln1g, L.ln1b, w.h, D, M, D, c.v_eps, dt, s));
+        RUN(gemm(ctx, s, w.h, D, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE));
+        vcla_attn_args a{};
+        a.q = w.qkv; a.k = (char*)w.qkv + (size_t)D * e; a.v = (char*)w.qkv + (size_t)2 * D * e; a.o = w.h;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)N * 3 * D; a.q_hs = a.k_hs = a.v_hs = d; a.q_rs = a.k_rs = a.v_rs = 3 * D;
+        a.o_bs = (int64_t)N * D; a.o_hs = d; a.o_rs = D;
+        a.B = B; a.H = H; a.Tq = N; a.Tk = N; a.D = d; a.scale = 1.0f / sqrtf((float)d); a.causal = 0;
+        RUN(vcla_attention(&a, dt, s));
+        RUN(gemm(ctx, s, w.h, D, L.wo, L.bo, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE));
+        RUN(vcla_layernorm(w.x, D, L.ln2g, L.ln2b, w.h, D, M, D, c.v_eps, dt, s));
+        RUN(gemm(ctx, s, w.h, D, L.w1, L.b1, nullptr, 0, w.mlp, c.v_inter, M, c.v_inter, D, VCLA_EPI_QUICK_GELU));
+        RUN(gemm(ctx, s, w.mlp, c.v_inter, L.w2, L.b2, w.x, D, w.x, D, M, D, c.v_inter, VCLA_EPI_NONE));
+        RUN(tap_copy(vit_tap, l, w.x, (size_t)M * D * e, s));
+    }
+    // post_layernorm over ALL tokens (models/visualcla/modeling_visualcla.py:284)
+    RUN(vcla_layernorm(w.x, D, ctx->vit_post_g, ctx->vit_post_b, w.h, D, M, D, c.v_eps, dt, s));
+    RUN(tap_copy(vit_tap, c.v_layers, w.h, (size_t)M * D * e, s));
+
+    // ---- resampler
+    const int Q = c.r_queries, Dr = c.r_hidden, Hr = c.r_heads, dr = Dr / Hr, KV = Q + N;
+    {
+        const int64_t n_per = (int64_t)Q * Dr;
+        dim3 grid((unsigned)((n_per + 255) / 256), B);
+        if (dt == VCLA_F32) bcast_rows_kernel<float><<<grid, 256, 0, s>>>((const float*)ctx->res_query, (float*)w.lat, n_per);
+        else bcast_rows_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)ctx->res_query, (bf16_t*)w.lat, n_per);
+        VCLA_CHECK_LAUNCH("bcast_rows_kernel");
+    }
+    const int Mq = B * Q;
+    for (int l = 0; l < c.r_layers; ++l) {
+        const ResLayer& L = ctx->res[l];
+        RUN(gemm(ctx, s, w.lat, Dr, L.wq, L.bq, nullptr, 0, w.q, Dr, Mq, Dr, Dr, VCLA_EPI_NONE));
+        // K/V source = cat([latents, image tokens]) (modeling_visual_resampler.py:315): two GEMMs write the two row ranges
+        RUN(gemm(ctx, s, w.lat, Dr, L.wkv, L.bkv, nullptr, 0, w.kv, 2 * Dr, Mq, 2 * Dr, Dr, VCLA_EPI_NONE, 0, Q, KV, 0));
+        RUN(gemm(ctx, s, w.h, Dr, L.wkv, L.bkv, nullptr, 0, w.kv, 2 * Dr, M, 2 * Dr, Dr, VCLA_EPI_NONE, 0, N, KV, Q));
+        vcla_attn_args a{};
+        a.q = w.q; a.k = w.kv; a.v = (char*)w.kv + (size_t)Dr * e; a.o = w.ao;
+        a.q_bs = (int64_t)Q * Dr; a.q_hs = dr; a.q_rs = Dr;
+        a.k_bs = a.v_bs = (int64_t)KV * 2 * Dr; a.k_hs = a.v_hs = dr; a.k_rs = a.v_rs = 2 * Dr;
+        a.o_bs = (int64_t)Q * Dr; a.o_hs = dr; a.o_rs = Dr;
+        a.B = B; a.H = Hr; a.Tq = Q; a.Tk = KV; a.D = dr; a.scale = 1.0f / sqrtf((float)dr); a.causal = 0;
+        RUN(vcla_attention(&a, dt, s));
+        RUN(gemm(ctx, s, w.ao, Dr, L.wo, L.bo, w.lat, Dr, w.t, Dr, Mq, Dr, Dr, VCLA_EPI_NONE));
+        RUN(vcla_layernorm(w.t, Dr, L.ln1g, L.ln1b, w.h2, Dr, Mq, Dr, c.r_eps, dt, s));
+        RUN(gemm(ctx, s, w.h2, Dr, L.w1, L.b1, nullptr, 0, w.ffn, c.r_inter, Mq, c.r_inter, Dr, VCLA_EPI_GELU_ERF));
+        RUN(gemm(ctx, s, w.ffn, c.r_inter, L.w2, L.b2, w.h2, Dr, w.t, Dr, Mq, Dr, c.r_inter, VCLA_EPI_NONE));
+        RUN(vcla_layernorm(w.t, Dr, L.ln2g, L.ln2b, w.lat, Dr, Mq, Dr, c.r_eps, dt, s));
+        RUN(tap_copy(res_tap, l, w.lat, (size_t)Mq * Dr * e, s));
+    }
+    // ---- projection into the text embedding space
+    RUN(gemm(ctx, s, w.lat, Dr, ctx->proj_w, ctx->proj_b, nullptr, 0, image_embeds, c.t_hidden, Mq, c.t_hidden, Dr, VCLA_EPI_NONE));
+    return VCLA_OK;
+}
+
+// ------------------------------------------------------------------ LLaMA decoder
+// One decoder layer over M = B*T rows held in ws.x (updated in place).
+static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const LlamaWs& w, int l, int B, int T, int pos0,
+                       const int32_t* pos_dev, void* kv_cache, int ctx_max, const int32_t* key_mask) {
+    const vcla_model_cfg& c = ctx->c;
+    const int dt = c.act_dtype;
+    const size_t e = esz(ctx);
+    const int D = c.t_hidden, H = c.t_heads, d = D / H, M = B * T;
+    const size_t per = (size_t)B * H * ctx_max * d * e;  // bytes of one K (or V) slab of one layer
+    char* kc = (char*)kv_cache + (size_t)(2 * l) * per;
+    char* vc = kc + per;
+    RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
+    RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE));
+    RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dt, s));
+    vcla_attn_args a{};
+    a.q = w.qkv; a.k = kc; a.v = vc; a.o = w.ao;
+    a.q_bs = (int64_t)T * 3 * D; a.q_hs = d; a.q_rs = 3 * D;
+    a.k_bs = a.v_bs = (int64_t)H * ctx_max * d; a.k_hs = a.v_hs = (int64_t)ctx_max * d; a.k_rs = a.v_rs = d;
+    a.o_bs = (int64_t)T * D; a.o_hs = d; a.o_rs = D;
+    a.B = B; a.H = H; a.Tq = T; a.D = d; a.scale = 1.0f / sqrtf((float)d); a.causal = 1;
+    a.key_mask = key_mask; a.key_mask_ld = ctx_max;
+    if (pos_dev) { a.Tk = ctx_max; a.tk_dev = pos_dev; a.tk_dev_add = pos0 + T; }
+    else a.Tk = pos0 + T;
+    RUN(vcla_attention(&a, dt, s));
+    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE));
+    RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
+    RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE));
+    return VCLA_OK;
+}
+
+extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache,
+                                  int ctx_max, const int32_t* key_mask, float* logits, int all_logits, void* ws,
+                                  size_t ws_bytes, void* layer_tap, void* stream) {
+    VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "llama_prefill: context not finalized");
+    VCLA_REQUIRE(inputs_embeds && kv_cache && ws, VCLA_ERR_BAD_ARG, "llama_prefill: null pointer");
+    const vcla_model_cfg& c = ctx->c;
+    VCLA_REQUIRE(B > 0 && T > 0 && pos0 >= 0 && pos0 + T <= ctx_max && ctx_max <= c.t_max_pos, VCLA_ERR_BAD_SHAPE,
+                 "llama_prefill: B=%d T=%d pos0=%d ctx_max=%d (max_pos %d)", B, T, pos0, ctx_max, c.t_max_pos);
+    VCLA_REQUIRE(ws_bytes >= vcla_llama_workspace_bytes(ctx, B, T), VCLA_ERR_WORKSPACE, "llama_prefill: workspace %zu < %zu bytes",
+                 ws_bytes, vcla_llama_workspace_bytes(ctx, B, T));
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = c.act_dtype;
+    const size_t e = esz(ctx);
+    const int D = c.t_hidden, M = B * T;
+    LlamaWs w;
+    carve_llama(ctx, B, T, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < c.t_layers; ++l) {
+        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, T, pos0, nullptr, kv_cache, ctx_max, key_mask));
+        RUN(tap_copy(layer_tap, l, w.x, (size_t)M * D * e, s));
+    }
+    if (all_logits) {
+        RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, M, D, c.t_eps, dt, s));
+        RUN(tap_copy(layer_tap, c.t_layers, w.h, (size_t)M * D * e, s));
+        if (logits)
+            RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, logits, c.t_vocab, M, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    } else if (logits) {
+        // last position of every sequence only: rows (b, T-1) -> hl [B, D]
+        RUN(vcla_rmsnorm((char*)w.x + (size_t)(T - 1) * D * e, (int64_t)T * D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, logits, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    }
+    return VCLA_OK;
+}
+
+static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
+                            int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
+                            int64_t* ids_out, const LlamaWs& w) {
+    const vcla_model_cfg& c = ctx->c;
+    const int dt = c.act_dtype;
+    const int D = c.t_hidden;
+    RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));
+    for (int l = 0; l < c.t_layers; ++l)
+        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask));
+    RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
+    float* lg = logits ? logits : w.logits;
+    RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
+    if (advance_pos && pos_dev) {
+        advance_pos_kernel<<<1, 1, 0, s>>>(pos_dev);
+        VCLA_CHECK_LAUNCH("advance_pos_kernel");
+    }
+    return VCLA_OK;
+}
+
+static int check_decode_args(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, const int32_t* pos_dev, void* kv_cache,
+                             int ctx_max, void* ws, size_t ws_bytes) {
+    VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "llama_decode: context not finalized");
+    VCLA_REQUIRE(ids_in && kv_cache && ws, VCLA_ERR_BAD_ARG, "llama_decode: null pointer");
+    VCLA_REQUIRE(B > 0 && pos0 >= 0 && ctx_max <= ctx->c.t_max_pos && (pos_dev || pos0 < ctx_max), VCLA_ERR_BAD_SHAPE,
+                 "llama_decode: B=%d pos0=%d ctx_max=%d (max_pos %d)", B, pos0, ctx_max, ctx->c.t_max_pos);
+    VCLA_REQUIRE(ws_bytes >= vcla_llama_workspace_bytes(ctx, B, 1), VCLA_ERR_WORKSPACE, "llama_decode: workspace %zu < %zu bytes",
+                 ws_bytes, vcla_llama_workspace_bytes(ctx, B, 1));
+    return VCLA_OK;
+}
+
+extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
+                                      int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask,
+                                      float* logits, int64_t* ids_out, void* ws, size_t ws_bytes, void* stream) {
+    RUN(check_decode_args(ctx, ids_in, B, pos0, pos_dev, kv_cache, ctx_max, ws, ws_bytes));
+    LlamaWs w;
+    carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
+                            logits, ids_out, w);
+}
+
+extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
+                                      void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
+                                      size_t ws_bytes, int use_graph, void* stream) {
+    RUN(check_decode_args(ctx, ids_in, B, pos0, pos_dev, kv_cache, ctx_max, ws, ws_bytes));
+    VCLA_REQUIRE(pos_dev && ids_out && n_steps >= 0, VCLA_ERR_BAD_ARG, "llama_decode_loop: needs pos_dev, ids_out, n_steps >= 0");
+    if (n_steps == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    LlamaWs w;
+    carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    // w.ids holds the current token of every sequence; each step consumes it and overwrites it with the argmax.
+    VCLA_CHECK_HIP(hipMemcpyAsync(w.ids, ids_in, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
+    // step_base: value of *pos_dev at the first step is unknown to the host -> the caller passes pos0 as the absolute
+    // position of the first decoded token and keeps *pos_dev == 0 at entry (documented in INTEGRATION.md).
+    const int step_base = 0;
+    auto one_step = [&](hipStream_t st) -> int {
+        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w));
+        record_ids_kernel<<<(B + 63) / 64, 64, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B);
+        VCLA_CHECK_LAUNCH("record_ids_kernel");
+        advance_pos_kernel<<<1, 1, 0, st>>>(pos_dev);
+        VCLA_CHECK_LAUNCH("advance_pos_kernel");
+        return VCLA_OK;
+    };
+    if (!use_graph || s == nullptr) {  // stream capture is illegal on the legacy default stream
+        for (int i = 0; i < n_steps; ++i) RUN(one_step(s));
+        return VCLA_OK;
+    }
+    // hipGraph path: capture one step once per (buffers, shapes) key, replay n_steps times.
+    auto& k = ctx->graph_key;
+    const bool same = ctx->graph_exec && k.ids == (const void*)w.ids && k.kv == kv_cache && k.mask == (const void*)key_mask &&
+                      k.ws == ws && k.out == (const void*)ids_out && k.B == B && k.pos0 == pos0 && k.ctx_max == ctx_max &&
+                      k.pos_dev == (const void*)pos_dev && k.step_base == step_base;
+    if (!same) {
+        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        VCLA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = one_step(s);
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { ctx->graph_exec = nullptr; return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+        k.ids = w.ids; k.kv = kv_cache; k.mask = key_mask; k.ws = ws; k.out = ids_out; k.B = B; k.pos0 = pos0;
+        k.ctx_max = ctx_max; k.pos_dev = pos_dev; k.step_base = step_base;
+    }
+    for (int i = 0; i < n_steps; ++i) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, s));
+    return VCLA_OK;
+}

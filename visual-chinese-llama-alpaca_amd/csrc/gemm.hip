@@ -1,0 +1,450 @@
+// gemm.hip -- C = epilogue(A . W^T + bias) (+ residual) for every Linear on the VisualCLA path.
+//
+//   A [M, K]  activations (bf16 or fp32), row stride lda
+//   W [N_pad, K] bf16 weights, K contiguous (both MFMA operands are read as 8 contiguous k = one 16-byte LDS read)
+//
+// Three kernels:
+//   gemm_mfma_kernel   bf16 x bf16 -> fp32 on v_mfma_f32_16x16x32_bf16; 128x128x64 workgroup tile, 4 waves
+//                      (2x2, 64x64 per wave = 4x4 MFMA tiles), LDS double buffer with an XOR swizzle that makes
+//                      the ds_read_b128 fragment reads conflict-free, global->register prefetch of tile k+1
+//                      under the MFMAs of tile k, XCD-aware tile order.  MFMA operands are swapped (W rows feed
+//                      the A port) so each lane ends up with 4 CONSECUTIVE output columns of one row -> 8/16-byte
+//                      epilogue stores, and the SwiGLU gate/up pair (16 packed rows apart) sits in the same lane.
+//   gemv_kernel        M <= 8 (decode): weight rows streamed once straight into registers with 16-byte
+//                      non-temporal loads, 4 rows per wave, wave-shuffle reduction.  HBM-bound by design.
+//   gemm_f32_kernel    fp32 activations (parity mode): classic 64x64x16 LDS-tiled FMA kernel.
+#include "vcla_common.h"
+
+// ------------------------------------------------------------------ shared epilogue math
+template <int EPI> __device__ __forceinline__ float epi_act(float x) {
+    if (EPI == VCLA_EPI_QUICK_GELU) return act_quick_gelu(x);
+    if (EPI == VCLA_EPI_GELU_ERF) return act_gelu_erf(x);
+    return x;
+}
+
+__device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
+    if (a.c_group_rows <= 0) return m;
+    return (int64_t)(m / a.c_group_rows) * a.c_group_stride + (m % a.c_group_rows) + a.c_row_offset;
+}
+
+// =================================================================== MFMA kernel
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 64
+
+// byte offset of 16-byte chunk `ch` (0..7) of row `row` inside a [128][64] bf16 tile, XOR-swizzled
+__device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GM_BM * GM_BK * 2];  // [buf][A|W][16 KiB]
+
+    // ---- tile assignment: XCD-aware (block b runs on XCD b % 8; give each XCD a contiguous run of tiles),
+    // then group 8 m-tiles per n-sweep so that A panels stay L2-resident while W panels stream.
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int GRP = 8;
+    const int per_grp = GRP * tiles_n;
+    const int g = bid / per_grp;
+    const int gm0 = g * GRP;
+    const int gsz = (tiles_m - gm0) < GRP ? (tiles_m - gm0) : GRP;
+    const int tm = gm0 + (bid % per_grp) % gsz;
+    const int tn = (bid % per_grp) / gsz;
+    const int m0 = tm * GM_BM, n0 = tn * GM_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- global -> register staging: 4 x 16 B per operand per thread
+    const bf16_t* Ag = (const bf16_t*)a.A;
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const bf16_t* aptr[4];
+    const bf16_t* wptr[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = i * 256 + tid;
+        const int row = id >> 3, ch = id & 7;
+        int am = m0 + row;
+        if (am >= a.M) am = a.M - 1;  // clamp: rows past M are computed on valid memory and never stored
+        aptr[i] = Ag + (int64_t)am * a.lda + ch * 8;
+        wptr[i] = Wg + (int64_t)(n0 + row) * a.K + ch * 8;  // W is padded to a multiple of 128 rows
+        soff[i] = lds_off(row, ch);
+    }
+    uint4 ra[4], rw[4];
+    const int nk = a.K / GM_BK;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const uint4*>(aptr[i]);
+        rw[i] = *reinterpret_cast<const uint4*>(wptr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint4*>(&lds[0][0][soff[i]]) = ra[i];
+        *reinterpret_cast<uint4*>(&lds[0][1][soff[i]]) = rw[i];
+    }
+    __syncthreads();
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: lane l reads row (l & 15) of a 16-row sub-tile, k-chunk (l >> 4) (+4 for the 2nd K=32 step)
+    const int frow = lane & 15, fch = lane >> 4;
+
+    auto compute_tile = [&](int cur) {
+        const unsigned char* As = lds[cur][0];
+        const unsigned char* Ws = lds[cur][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ar = wm * 64 + i * 16 + frow;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(ar, kk * 4 + fch));
+                const int wr = wn * 64 + i * 16 + frow;
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wr, kk * 4 + fch));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // steady state: prefetch tile kt+1 into registers, MFMA tile kt from LDS, then park the prefetch in the
+    // other LDS buffer; one barrier per K tile.  The last tile is peeled so the loop body is branch-free.
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int cur = kt & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + (int64_t)(kt + 1) * GM_BK);
+            rw[i] = *reinterpret_cast<const uint4*>(wptr[i] + (int64_t)(kt + 1) * GM_BK);
+        }
+        compute_tile(cur);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&lds[cur ^ 1][0][soff[i]]) = ra[i];
+            *reinterpret_cast<uint4*>(&lds[cur ^ 1][1][soff[i]]) = rw[i];
+        }
+        __syncthreads();
+    }
+    compute_tile((nk - 1) & 1);
+
+    // ---- epilogue.  acc[i][j][r] = C[m][n] with m = m0 + wm*64 + i*16 + (lane & 15),
+    //                                             n = n0 + wn*64 + j*16 + (lane >> 4)*4 + r
+    const int mrow = lane & 15, nq = (lane >> 4) * 4;
+    OutT* Cg = (OutT*)a.C;
+    constexpr bool kF32 = sizeof(OutT) == 4;
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
+    const bool vec_c = (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
+    const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + mrow;
+        if (m >= a.M) continue;
+        const int64_t crow = remap_row(a, m);
+#pragma unroll
+        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? 2 : 4); ++j) {
+            float v[4];
+            int n;  // first output column of this lane's 4
+            if constexpr (EPI == VCLA_EPI_SWIGLU) {
+                // packed tiles (2j, 2j+1) = (gate, up) of output columns (n0 + wn*64)/2 + j*16 + ...
+                n = (n0 + wn * 64) / 2 + j * 16 + nq;
+                const int np_ = n0 + wn * 64 + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
+                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
+                    v[r] = act_silu(gt) * up;
+                }
+            } else {
+                n = n0 + wn * 64 + j * 16 + nq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r];
+                    if (a.bias && n + r < a.N) x += a.bias[n + r];
+                    v[r] = epi_act<EPI>(x);
+                }
+            }
+            if (n >= n_out) continue;
+            if (a.residual) {
+                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
+                if (vec_r && n + 3 < n_out) {
+                    float rv[4];
+                    Act<bf16_t>::ld4(rp, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < n_out) v[r] += bf2f(rp[r]);
+                }
+            }
+            OutT* cp = Cg + crow * a.ldc + n;
+            if (vec_c && n + 3 < n_out) {
+                Act<OutT>::st4(cp, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out) Act<OutT>::st(cp + r, v[r]);
+            }
+        }
+    }
+}
+
+// =================================================================== GEMV kernel (M <= 8)
+// x [MB, K] act dtype; each wave owns 4 weight rows (SWIGLU: 2 gate rows + their 2 up rows), lanes stride K by 8.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    bf8_to_f32(t, v);
+}
+
+__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+template <typename T, typename OutT, int MB, int EPI>
+__global__ __launch_bounds__(256) void gemv_kernel(vcla_gemm_args a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave index
+    int rows[4];
+    int nvalid;  // rows / outputs this wave really owns
+    if constexpr (EPI == VCLA_EPI_SWIGLU) {
+        const int j0 = gw * 2;  // output columns j0, j0+1
+        nvalid = (a.N / 2 - j0) < 2 ? (a.N / 2 - j0) : 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = j0 + r;
+            rows[r] = (j >> 4) * 32 + (j & 15);  // gate row in the 16-interleaved packing
+            rows[r + 2] = rows[r] + 16;          // matching up row
+        }
+    } else {
+        nvalid = (a.N - gw * 4) < 4 ? (a.N - gw * 4) : 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = gw * 4 + r;
+    }
+    if (nvalid <= 0) return;  // wave-uniform
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const T* X = (const T*)a.A;
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wp[r] = Wg + (int64_t)rows[r] * a.K;  // rows beyond N stay inside the 128-row padding
+
+    float acc[4][MB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+
+#pragma unroll 2
+    for (int k = lane * 8; k < a.K; k += 512) {
+        uint4 w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = ldg_nt(wp[r] + k);
+        float xv[MB][8];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) load8<T>(X + (int64_t)m * a.lda + k, xv[m]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wf[8];
+            bf8_to_f32(w[r], wf);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][m] += wf[e] * xv[m][e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
+
+    // lane (m * 4 + r) writes output (m, r)
+    OutT* Cg = (OutT*)a.C;
+    if constexpr (EPI == VCLA_EPI_SWIGLU) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (lane == m * 4 + r && r < nvalid) {
+                    float gt = acc[r][m], up = acc[r + 2][m];
+                    if (a.bias) { gt += a.bias[rows[r]]; up += a.bias[rows[r + 2]]; }
+                    float v = act_silu(gt) * up;
+                    const int n = gw * 2 + r;
+                    if (a.residual) v += Act<T>::ld((const T*)a.residual + (int64_t)m * a.ldr + n);
+                    Act<OutT>::st(Cg + remap_row(a, m) * a.ldc + n, v);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (lane == m * 4 + r && r < nvalid) {
+                    float v = acc[r][m];
+                    const int n = rows[r];
+                    if (a.bias) v += a.bias[n];
+                    v = epi_act<EPI>(v);
+                    if (a.residual) v += Act<T>::ld((const T*)a.residual + (int64_t)m * a.ldr + n);
+                    Act<OutT>::st(Cg + remap_row(a, m) * a.ldc + n, v);
+                }
+            }
+    }
+}
+
+// =================================================================== fp32-activation tile kernel (parity mode)
+// 64x64x16 tile, 256 threads, thread (ty, tx) computes rows ty+16i, columns tx+16j (so SWIGLU pairs are thread-local)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(vcla_gemm_args a) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Ws[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float* Ag = (const float*)a.A;
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    int am = m0 + lrow;
+    if (am >= a.M) am = a.M - 1;
+    const float* ap = Ag + (int64_t)am * a.lda + lk;
+    const bf16_t* wp = Wg + (int64_t)(n0 + lrow) * a.K + lk;  // padded rows exist up to a multiple of 128
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 16) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + k0);
+        float wv[4];
+        Act<bf16_t>::ld4(wp + k0, wv);
+        As[lk][lrow] = av.x; As[lk + 1][lrow] = av.y; As[lk + 2][lrow] = av.z; As[lk + 3][lrow] = av.w;
+        Ws[lk][lrow] = wv[0]; Ws[lk + 1][lrow] = wv[1]; Ws[lk + 2][lrow] = wv[2]; Ws[lk + 3][lrow] = wv[3];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float av4[4], wv4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av4[i] = As[k][ty + 16 * i]; wv4[i] = Ws[k][tx + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av4[i], wv4[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* Cg = (float*)a.C;
+    const float* Rg = (const float*)a.residual;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 16 * i;
+        if (m >= a.M) continue;
+        const int64_t crow = remap_row(a, m);
+        if constexpr (EPI == VCLA_EPI_SWIGLU) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int pg = n0 + tx + 32 * jp;  // packed gate column, up = +16
+                const int n = (n0 / 2) + tx + 16 * jp;
+                if (n >= a.N / 2) continue;
+                float gt = acc[i][2 * jp], up = acc[i][2 * jp + 1];
+                if (a.bias) { gt += a.bias[pg]; up += a.bias[pg + 16]; }
+                float v = act_silu(gt) * up;
+                if (Rg) v += Rg[(int64_t)m * a.ldr + n];
+                Cg[crow * a.ldc + n] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + tx + 16 * j;
+                if (n >= a.N) continue;
+                float v = acc[i][j];
+                if (a.bias) v += a.bias[n];
+                v = epi_act<EPI>(v);
+                if (Rg) v += Rg[(int64_t)m * a.ldr + n];
+                Cg[crow * a.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// =================================================================== host dispatch
+template <int EPI, typename OutT>
+static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
+    const int tiles_m = (a->M + GM_BM - 1) / GM_BM, tiles_n = (a->N + GM_BN - 1) / GM_BN;
+    gemm_mfma_kernel<EPI, OutT><<<tiles_m * tiles_n, 256, 0, s>>>(*a, tiles_m, tiles_n);
+    VCLA_CHECK_LAUNCH("gemm_mfma_kernel");
+    return VCLA_OK;
+}
+
+template <typename T, typename OutT, int EPI>
+static int launch_gemv(const vcla_gemm_args* a, hipStream_t s) {
+    const int n_units = (EPI == VCLA_EPI_SWIGLU) ? (a->N / 2 + 1) / 2 : (a->N + 3) / 4;  // waves needed
+    const int blocks = (n_units + 3) / 4;
+#define GEMV_CASE(MBV) \
+    case MBV: gemv_kernel<T, OutT, MBV, EPI><<<blocks, 256, 0, s>>>(*a); break;
+    switch (a->M) {
+        GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8)
+        default: return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemv: M=%d > 8", a->M);
+    }
+#undef GEMV_CASE
+    VCLA_CHECK_LAUNCH("gemv_kernel");
+    return VCLA_OK;
+}
+
+template <int EPI>
+static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStream_t s) {
+    if (kernel == 1) {
+        return a->out_f32 ? launch_mfma<EPI, float>(a, s) : launch_mfma<EPI, bf16_t>(a, s);
+    } else if (kernel == 2) {
+        if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
+        return a->out_f32 ? launch_gemv<bf16_t, float, EPI>(a, s) : launch_gemv<bf16_t, bf16_t, EPI>(a, s);
+    } else {
+        dim3 grid((a->N + 63) / 64, (a->M + 63) / 64);
+        gemm_f32_kernel<EPI><<<grid, 256, 0, s>>>(*a);
+        VCLA_CHECK_LAUNCH("gemm_f32_kernel");
+        return VCLA_OK;
+    }
+}
+
+extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
+    VCLA_REQUIRE(a, VCLA_ERR_BAD_ARG, "gemm: null args");
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
+    VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
+                 "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
+    VCLA_REQUIRE(a->A && a->W && a->C, VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE(a->epilogue >= VCLA_EPI_NONE && a->epilogue <= VCLA_EPI_SWIGLU, VCLA_ERR_BAD_ARG, "gemm: bad epilogue %d",
+                 a->epilogue);
+    VCLA_REQUIRE(a->epilogue != VCLA_EPI_SWIGLU || a->N % 32 == 0, VCLA_ERR_BAD_SHAPE,
+                 "gemm: SWIGLU needs N %% 32 == 0 (got %d)", a->N);
+    const int64_t aa = dtype == VCLA_F32 ? 4 : 8;
+    VCLA_REQUIRE(a->lda % aa == 0 && a->lda >= a->K && vcla_aligned(a->A, 16) && vcla_aligned(a->W, 16), VCLA_ERR_BAD_SHAPE,
+                 "gemm: A/W must be 16-byte aligned with lda %% %lld == 0 (lda=%lld)", (long long)aa, (long long)a->lda);
+    if (a->M == 0) return VCLA_OK;
+    int kernel = a->force_kernel;
+    if (kernel == 0) kernel = (a->M <= 8) ? 2 : (dtype == VCLA_F32 ? 3 : 1);
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 3, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(!(kernel == 1 && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernel needs bf16 activations");
+    VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
+    VCLA_REQUIRE(!(kernel == 2 && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
+    hipStream_t s = (hipStream_t)stream;
+    switch (a->epilogue) {
+        case VCLA_EPI_NONE: return dispatch_epi<VCLA_EPI_NONE>(a, dtype, kernel, s);
+        case VCLA_EPI_QUICK_GELU: return dispatch_epi<VCLA_EPI_QUICK_GELU>(a, dtype, kernel, s);
+        case VCLA_EPI_GELU_ERF: return dispatch_epi<VCLA_EPI_GELU_ERF>(a, dtype, kernel, s);
+        default: return dispatch_epi<VCLA_EPI_SWIGLU>(a, dtype, kernel, s);
+    }
+}

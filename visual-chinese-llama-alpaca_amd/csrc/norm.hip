@@ -1,0 +1,169 @@
+// norm.hip -- LayerNorm / RMSNorm / ViT embedding assembly.  HBM-bound row kernels:
+// one 256-thread workgroup per row, the row is staged once through LDS as fp32 (one HBM read,
+// one HBM write per element), statistics in fp32 with a two-pass variance.
+#include "vcla_common.h"
+
+#define NORM_MAX_COLS 8192
+
+// load row -> LDS (fp32) with 4-wide vector loads when aligned
+template <typename T>
+__device__ __forceinline__ void stage_row(const T* __restrict__ x, float* row, int cols, bool vec_ok) {
+    if (vec_ok) {
+        for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) {
+            float v[4];
+            Act<T>::ld4(x + c, v);
+            row[c] = v[0]; row[c + 1] = v[1]; row[c + 2] = v[2]; row[c + 3] = v[3];
+        }
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) row[c] = Act<T>::ld(x + c);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void layernorm_finish(float* row, float* red, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, T* __restrict__ y, int cols,
+                                                 float eps, bool vec_ok) {
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += row[c];
+    const float mean = block_sum_256(s, red) / (float)cols;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float d = row[c] - mean;
+        q += d * d;
+    }
+    const float var = block_sum_256(q, red) / (float)cols;
+    const float rstd = rsqrtf(var + eps);
+    if (vec_ok) {
+        for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (row[c + e] - mean) * rstd * gamma[c + e] + beta[c + e];
+            Act<T>::st4(y + c, v);
+        }
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256)
+            Act<T>::st(y + c, (row[c] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y,
+                                                        int64_t ldy, int cols, float eps, int vec_ok) {
+    __shared__ float row[NORM_MAX_COLS];
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    stage_row<T>(x + r * ldx, row, cols, vec_ok);
+    __syncthreads();
+    layernorm_finish<T>(row, red, gamma, beta, y + r * ldy, cols, eps, vec_ok);
+}
+
+// LlamaRMSNorm: fp32 statistics; normalised value rounded to the activation dtype BEFORE the gain multiply
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ gamma, T* __restrict__ y,
+                                                      int64_t ldy, int cols, float eps, int vec_ok) {
+    __shared__ float row[NORM_MAX_COLS];
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    stage_row<T>(x + r * ldx, row, cols, vec_ok);
+    __syncthreads();
+    float q = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) q += row[c] * row[c];
+    const float rstd = rsqrtf(block_sum_256(q, red) / (float)cols + eps);
+    T* yr = y + r * ldy;
+    if (vec_ok) {
+        for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gamma[c + e] * Act<T>::rnd(row[c + e] * rstd);
+            Act<T>::st4(yr + c, v);
+        }
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) Act<T>::st(yr + c, gamma[c] * Act<T>::rnd(row[c] * rstd));
+    }
+}
+
+// ViT input assembly: row (b, n): n == 0 -> class embedding, else patch embed (b, n-1); + position emb; pre-LN
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ patch, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y, int np,
+                                                           int D, float eps, int vec_ok) {
+    __shared__ float row[NORM_MAX_COLS];
+    __shared__ float red[8];
+    const int N = np + 1;
+    const int b = blockIdx.x / N, n = blockIdx.x % N;
+    const float* pr = pos + (int64_t)n * D;
+    if (n == 0) {
+        for (int c = threadIdx.x; c < D; c += 256) row[c] = Act<T>::rnd(cls[c] + pr[c]);
+    } else {
+        const T* src = patch + ((int64_t)b * np + (n - 1)) * D;
+        for (int c = threadIdx.x; c < D; c += 256) row[c] = Act<T>::rnd(Act<T>::ld(src + c) + pr[c]);
+    }
+    __syncthreads();
+    layernorm_finish<T>(row, red, gamma, beta, y + (int64_t)blockIdx.x * D, D, eps, vec_ok);
+}
+
+// ------------------------------------------------------------------ host entry points
+static inline bool vec4_ok(const void* p, int64_t ld, int cols, int dtype) {
+    const size_t a = dtype == VCLA_F32 ? 16 : 8;
+    return cols % 4 == 0 && ld % 4 == 0 && vcla_aligned(p, a);
+}
+
+extern "C" int vcla_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                              int64_t ldy, int rows, int cols, float eps, int dtype, void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "layernorm: bad dtype %d", dtype);
+    VCLA_REQUIRE(rows >= 0 && cols > 0 && cols <= NORM_MAX_COLS, VCLA_ERR_BAD_SHAPE,
+                 "layernorm: rows=%d cols=%d (max cols %d)", rows, cols, NORM_MAX_COLS);
+    VCLA_REQUIRE(x && y && gamma && beta, VCLA_ERR_BAD_ARG, "layernorm: null pointer");
+    if (rows == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int v = vec4_ok(x, ldx, cols, dtype) && vec4_ok(y, ldy, cols, dtype);
+    if (dtype == VCLA_F32)
+        layernorm_kernel<float><<<rows, 256, 0, s>>>((const float*)x, ldx, gamma, beta, (float*)y, ldy, cols, eps, v);
+    else
+        layernorm_kernel<bf16_t><<<rows, 256, 0, s>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, cols, eps, v);
+    VCLA_CHECK_LAUNCH("layernorm_kernel");
+    return VCLA_OK;
+}
+
+extern "C" int vcla_rmsnorm(const void* x, int64_t ldx, const float* gamma, void* y, int64_t ldy, int rows,
+                            int cols, float eps, int dtype, void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "rmsnorm: bad dtype %d", dtype);
+    VCLA_REQUIRE(rows >= 0 && cols > 0 && cols <= NORM_MAX_COLS, VCLA_ERR_BAD_SHAPE,
+                 "rmsnorm: rows=%d cols=%d (max cols %d)", rows, cols, NORM_MAX_COLS);
+    VCLA_REQUIRE(x && y && gamma, VCLA_ERR_BAD_ARG, "rmsnorm: null pointer");
+    if (rows == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int v = vec4_ok(x, ldx, cols, dtype) && vec4_ok(y, ldy, cols, dtype);
+    if (dtype == VCLA_F32)
+        rmsnorm_kernel<float><<<rows, 256, 0, s>>>((const float*)x, ldx, gamma, (float*)y, ldy, cols, eps, v);
+    else
+        rmsnorm_kernel<bf16_t><<<rows, 256, 0, s>>>((const bf16_t*)x, ldx, gamma, (bf16_t*)y, ldy, cols, eps, v);
+    VCLA_CHECK_LAUNCH("rmsnorm_kernel");
+    return VCLA_OK;
+}
+
+extern "C" int vcla_vit_assemble(const void* patch_embeds, const float* cls, const float* pos, const float* gamma,
+                                 const float* beta, void* y, int B, int np, int D, float eps, int dtype,
+                                 void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "vit_assemble: bad dtype %d", dtype);
+    VCLA_REQUIRE(B >= 0 && np > 0 && D > 0 && D <= NORM_MAX_COLS, VCLA_ERR_BAD_SHAPE,
+                 "vit_assemble: B=%d np=%d D=%d", B, np, D);
+    VCLA_REQUIRE(patch_embeds && cls && pos && gamma && beta && y, VCLA_ERR_BAD_ARG, "vit_assemble: null pointer");
+    if (B == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * (np + 1);
+    const int v = vec4_ok(y, D, D, dtype);
+    if (dtype == VCLA_F32)
+        vit_assemble_kernel<float><<<rows, 256, 0, s>>>((const float*)patch_embeds, cls, pos, gamma, beta, (float*)y,
+                                                        np, D, eps, v);
+    else
+        vit_assemble_kernel<bf16_t><<<rows, 256, 0, s>>>((const bf16_t*)patch_embeds, cls, pos, gamma, beta,
+                                                         (bf16_t*)y, np, D, eps, v);
+    VCLA_CHECK_LAUNCH("vit_assemble_kernel");
+    return VCLA_OK;
+}

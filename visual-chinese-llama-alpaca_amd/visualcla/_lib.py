@@ -1,0 +1,221 @@
+"""ctypes binding of libvisualcla_hip.so (include/visualcla_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or the device is
+not a gfx950, every entry point raises.  Tensors stay torch-owned; only raw device pointers,
+sizes and the current HIP stream cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+VCLA_F32, VCLA_BF16 = 0, 1
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SWIGLU = 0, 1, 2, 3
+
+_ERR_NAMES = {1: "BAD_SHAPE", 2: "BAD_DTYPE", 3: "UNSUPPORTED_ARCH", 4: "HIP", 5: "BAD_ARG", 6: "WORKSPACE",
+              7: "MISSING_TENSOR"}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("VCLA_LIB", os.path.join(_HERE, "libvisualcla_hip.so"))
+
+
+class VclaError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("epilogue", C.c_int), ("out_f32", C.c_int),
+        ("c_group_rows", C.c_int), ("c_group_stride", C.c_int), ("c_row_offset", C.c_int),
+        ("force_kernel", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+        ("q_bs", C.c_int64), ("q_hs", C.c_int64), ("q_rs", C.c_int64),
+        ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
+        ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_rs", C.c_int64),
+        ("o_bs", C.c_int64), ("o_hs", C.c_int64), ("o_rs", C.c_int64),
+        ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float), ("causal", C.c_int),
+        ("key_mask", C.c_void_p), ("key_mask_ld", C.c_int64),
+        ("tk_dev", C.c_void_p), ("tk_dev_add", C.c_int),
+        ("force_kernel", C.c_int),
+    ]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [
+        ("act_dtype", C.c_int),
+        ("v_hidden", C.c_int), ("v_layers", C.c_int), ("v_heads", C.c_int), ("v_inter", C.c_int),
+        ("v_patch", C.c_int), ("v_image", C.c_int), ("v_channels", C.c_int), ("v_eps", C.c_float),
+        ("r_hidden", C.c_int), ("r_layers", C.c_int), ("r_heads", C.c_int), ("r_inter", C.c_int),
+        ("r_queries", C.c_int), ("r_eps", C.c_float),
+        ("t_hidden", C.c_int), ("t_layers", C.c_int), ("t_heads", C.c_int), ("t_inter", C.c_int),
+        ("t_vocab", C.c_int), ("t_max_pos", C.c_int), ("t_eps", C.c_float), ("t_rope_theta", C.c_float),
+    ]
+
+
+# every symbol include/visualcla_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SYMBOLS = {
+    "vcla_version": (_i, []),
+    "vcla_last_error": (C.c_char_p, []),
+    "vcla_device_check": (_i, []),
+    "vcla_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
+    "vcla_rmsnorm": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
+    "vcla_gemm": (_i, [C.POINTER(GemmArgs), _i, _vp]),
+    "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "vcla_attention": (_i, [C.POINTER(AttnArgs), _i, _vp]),
+    "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
+    "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
+    "vcla_ctx_destroy": (None, [_vp]),
+    "vcla_ctx_set_tensor": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "vcla_ctx_finalize": (_i, [_vp]),
+    "vcla_vision_workspace_bytes": (_sz, [_vp, _i]),
+    "vcla_llama_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "vcla_kv_cache_bytes": (_sz, [_vp, _i, _i]),
+    "vcla_vision_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "vcla_llama_prefill": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
+    "vcla_llama_decode_step": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vcla_llama_decode_loop": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises VclaError if it is absent -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VclaError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+            f"(or `make -C visual-chinese-llama-alpaca_amd/csrc`). The VisualCLA HIP path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().vcla_last_error().decode("utf-8", "replace")
+        kind = _ERR_NAMES.get(rc, str(rc))
+        if rc in (1, 2, 5):
+            raise ValueError(f"visualcla_hip[{kind}]: {msg}")
+        raise VclaError(f"visualcla_hip[{kind}]: {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return VCLA_F32
+    if dt == torch.bfloat16:
+        return VCLA_BF16
+    raise ValueError(f"activation dtype must be float32 or bfloat16, got {dt}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_device() -> None:
+    """Fail loudly when there is no usable MI355X."""
+    if not torch.cuda.is_available():
+        raise VclaError("no HIP device visible: the VisualCLA HIP path needs an MI355X (gfx950); there is no CPU fallback")
+    check(load().vcla_device_check())
+
+
+# ------------------------------------------------------------------ primitive wrappers (used by tests / tools)
+def layernorm(x, gamma, beta, eps, out=None):
+    lib = load()
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    x2 = x.reshape(rows, cols)
+    assert x2.stride(1) == 1
+    out = torch.empty_like(x2) if out is None else out
+    check(lib.vcla_layernorm(ptr(x2), x2.stride(0), ptr(gamma), ptr(beta), ptr(out), out.stride(0), rows, cols,
+                             eps, dtype_code(x.dtype), stream_ptr()))
+    return out.view(x.shape)
+
+
+def rmsnorm(x, gamma, eps, out=None):
+    lib = load()
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    x2 = x.reshape(rows, cols)
+    out = torch.empty_like(x2) if out is None else out
+    check(lib.vcla_rmsnorm(ptr(x2), x2.stride(0), ptr(gamma), ptr(out), out.stride(0), rows, cols, eps,
+                           dtype_code(x.dtype), stream_ptr()))
+    return out.view(x.shape)
+
+
+def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
+         group_rows=0, group_stride=0, row_offset=0):
+    """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out]."""
+    lib = load()
+    M, K = a.shape
+    n_out = n // 2 if epilogue == EPI_SWIGLU else n
+    if out is None:
+        odt = torch.float32 if (out_f32 or a.dtype == torch.float32) else torch.bfloat16
+        out = torch.empty(M, n_out, dtype=odt, device=a.device)
+    args = GemmArgs()
+    args.A, args.lda = ptr(a), a.stride(0)
+    args.W, args.bias = ptr(w_packed), ptr(bias)
+    args.residual, args.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
+    args.C, args.ldc = ptr(out), out.stride(0)
+    args.M, args.N, args.K = M, n, K
+    args.epilogue, args.out_f32 = epilogue, int(bool(out_f32))
+    args.c_group_rows, args.c_group_stride, args.c_row_offset = group_rows, group_stride, row_offset
+    args.force_kernel = force_kernel
+    check(lib.vcla_gemm(C.byref(args), dtype_code(a.dtype), stream_ptr()))
+    return out
+
+
+def attention(q, k, v, scale, causal=False, key_mask=None, out=None, force_kernel=0):
+    """q [B,H,Tq,D], k/v [B,H,Tk,D] (any strides with unit last stride) -> o [B,Tq,H*D]."""
+    lib = load()
+    B, H, Tq, D = q.shape
+    Tk = k.shape[2]
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if out is None:
+        out = torch.empty(B, Tq, H * D, dtype=q.dtype, device=q.device)
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(out)
+    a.q_bs, a.q_hs, a.q_rs = q.stride(0), q.stride(1), q.stride(2)
+    a.k_bs, a.k_hs, a.k_rs = k.stride(0), k.stride(1), k.stride(2)
+    a.v_bs, a.v_hs, a.v_rs = v.stride(0), v.stride(1), v.stride(2)
+    a.o_bs, a.o_hs, a.o_rs = out.stride(0), D, out.stride(1)
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.scale, a.causal = float(scale), int(bool(causal))
+    a.key_mask, a.key_mask_ld = ptr(key_mask), (key_mask.stride(0) if key_mask is not None else 0)
+    a.tk_dev, a.tk_dev_add, a.force_kernel = None, 0, force_kernel
+    check(lib.vcla_attention(C.byref(a), dtype_code(q.dtype), stream_ptr()))
+    return out
+
+
+def argmax(logits):
+    lib = load()
+    B, V = logits.shape
+    out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    check(lib.vcla_argmax(ptr(logits), logits.stride(0), ptr(out), B, V, stream_ptr()))
+    return out

@@ -1,0 +1,638 @@
+"""VisualCLAModel on MI355X: same Python surface as the reference's
+models/visualcla/modeling_visualcla.py (forward :264-330, generate :334-392, loaders :121-261), with every
+tensor operation of the hot path executed by libvisualcla_hip.so (hand-written gfx950 kernels).
+
+Host responsibilities kept here (Python, like the reference): argument plumbing, image-slot validation
+(ValueError convention of modeling_visualcla.py:300-302/:366-367), the generation loop's control flow
+(EOS / stopping criteria / logits processors), checkpoint reading.  There is no CPU or eager-PyTorch
+fallback for the arithmetic: without the shared library and a gfx950 device the model raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import _lib
+from .configuration_visualcla import VisualCLAConfig
+from .weights import pack_state_dict, random_packed, unpack_state_dict
+
+
+def _act_dtype(torch_dtype) -> torch.dtype:
+    """fp32 -> fp32 parity mode; fp16 / bf16 -> the bf16 product path (the reference's GPU dtype is fp16,
+    modeling_utils.py:88; MI355X MFMA kernels here are bf16)."""
+    if torch_dtype in (None, torch.float16, torch.bfloat16, "float16", "bfloat16", "auto"):
+        return torch.bfloat16
+    if torch_dtype in (torch.float32, "float32"):
+        return torch.float32
+    raise ValueError(f"unsupported torch_dtype {torch_dtype}")
+
+
+class VclaCache:
+    """KV cache handle returned as `past_key_values`: one device tensor [L, 2, B, H, ctx_max, d]."""
+
+    def __init__(self, kv: torch.Tensor, length: int, ctx_max: int):
+        self.kv, self.length, self.ctx_max = kv, length, ctx_max
+
+    def get_seq_length(self) -> int:
+        return self.length
+
+
+class _Embedding:
+    """Minimal stand-in for nn.Embedding so `model.get_input_embeddings().weight` keeps working
+    (scripts/inference/inference.py:67, scripts/merge_llama_with_visualcla_lora.py:60)."""
+
+    def __init__(self, weight: torch.Tensor):
+        self.weight = weight
+        self.num_embeddings, self.embedding_dim = weight.shape
+
+    def __call__(self, ids: torch.Tensor) -> torch.Tensor:
+        raise RuntimeError("token embedding is fused into vcla_embed_splice; call VisualCLAModel.forward/generate")
+
+
+class VisualCLAModel:
+    config_class = VisualCLAConfig
+    base_model_prefix = "visualcla"
+
+    # ------------------------------------------------------------------ construction
+    def __init__(self, config: VisualCLAConfig, packed: Optional[Dict[str, torch.Tensor]] = None,
+                 device: Union[str, torch.device, None] = None, torch_dtype=torch.bfloat16, seed: int = 0):
+        if not config.use_visual_resampler:
+            raise ValueError("VisualCLA-7B always uses the visual resampler (use_visual_resampler=True)")
+        _lib.require_device()
+        self.config = config
+        self._device = torch.device(device if device is not None else "cuda:0")
+        if self._device.type != "cuda":
+            raise _lib.VclaError("VisualCLAModel runs on an MI355X only (device must be cuda:N); there is no CPU fallback")
+        self._dtype = _act_dtype(torch_dtype)
+        self.image_at_head = True          # reference default (modeling_visualcla.py:108); the loader flips it
+        self.tokenizer = None
+        self.image_processor = None
+        self.num_patch = config.visual_resampler_config["num_query_tokens"]
+        self.generation_config = None
+        self._ctx = None
+        self._ws: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(self._device):
+            self._packed = packed if packed is not None else random_packed(config, self._device, self._dtype, seed)
+            self._build_ctx()
+        t, v = config.text_config, config.vision_config
+        self.vision_embed_dim, self.text_embed_dim = v["hidden_size"], t["hidden_size"]
+        self.vision_model = SimpleNamespace(config=SimpleNamespace(**v))
+        self.text_model = SimpleNamespace(config=SimpleNamespace(**t), get_input_embeddings=self.get_input_embeddings,
+                                          get_output_embeddings=self.get_output_embeddings)
+
+    def _cfg_struct(self) -> _lib.ModelCfg:
+        v, r, t = self.config.vision_config, self.config.visual_resampler_config, self.config.text_config
+        if t.get("num_key_value_heads") not in (None, t["num_attention_heads"]):
+            raise ValueError("grouped-query attention is not used by Chinese-Alpaca-7B and is not supported")
+        c = _lib.ModelCfg()
+        c.act_dtype = _lib.dtype_code(self._dtype)
+        c.v_hidden, c.v_layers, c.v_heads = v["hidden_size"], v["num_hidden_layers"], v["num_attention_heads"]
+        c.v_inter, c.v_patch, c.v_image = v["intermediate_size"], v["patch_size"], v["image_size"]
+        c.v_channels, c.v_eps = v.get("num_channels", 3), v.get("layer_norm_eps", 1e-5)
+        c.r_hidden, c.r_layers, c.r_heads = r["hidden_size"], r["num_hidden_layers"], r["num_attention_heads"]
+        c.r_inter, c.r_queries, c.r_eps = r["intermediate_size"], r["num_query_tokens"], r.get("layer_norm_eps", 1e-12)
+        c.t_hidden, c.t_layers, c.t_heads = t["hidden_size"], t["num_hidden_layers"], t["num_attention_heads"]
+        c.t_inter, c.t_vocab, c.t_max_pos = t["intermediate_size"], t["vocab_size"], t["max_position_embeddings"]
+        c.t_eps = t.get("rms_norm_eps", 1e-6)
+        c.t_rope_theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
+        if v.get("hidden_act", "quick_gelu") != "quick_gelu" or r.get("hidden_act", "gelu") != "gelu":
+            raise ValueError("only quick_gelu (CLIP) and gelu (resampler) activations are implemented")
+        return c
+
+    def _build_ctx(self) -> None:
+        lib = _lib.load()
+        self._destroy_ctx()
+        handle = C.c_void_p()
+        cfg = self._cfg_struct()
+        _lib.check(lib.vcla_ctx_create(C.byref(cfg), C.byref(handle)))
+        self._ctx = handle
+        for name, t in self._packed.items():
+            if not t.is_contiguous():
+                raise ValueError(f"packed tensor {name} is not contiguous")
+            _lib.check(lib.vcla_ctx_set_tensor(self._ctx, name.encode(), t.data_ptr(), t.numel() * t.element_size()))
+        _lib.check(lib.vcla_ctx_finalize(self._ctx))
+        self._pos_dev = torch.zeros(1, dtype=torch.int32, device=self._device)
+
+    def _destroy_ctx(self) -> None:
+        if getattr(self, "_ctx", None):
+            _lib.load().vcla_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._destroy_ctx()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_state_dict(cls, config: VisualCLAConfig, state_dict: Dict[str, torch.Tensor], device=None,
+                        torch_dtype=torch.bfloat16) -> "VisualCLAModel":
+        dev = torch.device(device if device is not None else "cuda:0")
+        packed = pack_state_dict(state_dict, config, dev, _act_dtype(torch_dtype))
+        return cls(config, packed, dev, torch_dtype)
+
+    @classmethod
+    def from_random(cls, config: VisualCLAConfig, device=None, torch_dtype=torch.bfloat16, seed: int = 0):
+        return cls(config, None, device, torch_dtype, seed)
+
+    @staticmethod
+    def _read_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
+        sd: Dict[str, torch.Tensor] = {}
+        files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))) + sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise ValueError(f"no pytorch_model*.bin / *.safetensors under {path}")
+        for f in files:
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd.update(load_file(f, device="cpu"))
+            else:
+                sd.update(torch.load(f, map_location="cpu", weights_only=True))
+        return sd
+
+    @classmethod
+    def from_merged_pretrained(cls, visualcla_model_name_or_path: str = None, *args, torch_dtype=torch.float16,
+                               default_device=None, device_map=None, load_in_8bit=False, **kwargs):
+        """Reads the merged on-disk layout written by scripts/merge_llama_with_visualcla_lora.py:87-97:
+        `<dir>/config.json`, `<dir>/pytorch_model*.bin` (visual_resampler.* + image_projection_layer.*),
+        `<dir>/text_encoder/`, `<dir>/vision_encoder/` (modeling_visualcla.py:141-179)."""
+        import json
+        path = visualcla_model_name_or_path
+        if path is None or not os.path.isdir(path):
+            raise ValueError(f"visualcla model path '{path}' is not a local directory (no network access here)")
+        if load_in_8bit:
+            raise ValueError("load_in_8bit (bitsandbytes, CUDA-only) is not available; weights are loaded as bf16")
+        config = VisualCLAConfig.from_pretrained(path)
+        top = cls._read_checkpoint_dir(path)
+        sd = {k: v for k, v in top.items() if k.startswith(("visual_resampler.", "image_projection_layer."))}
+        for sub, prefix in (("text_encoder", "text_model."), ("vision_encoder", "vision_model.")):
+            d = os.path.join(path, sub)
+            with open(os.path.join(d, "config.json")) as f:
+                sub_cfg = json.load(f)
+            if sub == "text_encoder":
+                config.text_config = sub_cfg
+            else:
+                config.vision_config = sub_cfg.get("vision_config", sub_cfg)
+            for k, v in cls._read_checkpoint_dir(d).items():
+                sd[prefix + k] = v
+        return cls.from_state_dict(config, sd, default_device, torch_dtype)
+
+    @classmethod
+    def from_vision_text_pretrained(cls, vision_model_name_or_path: str = None, text_model_name_or_path: str = None,
+                                    visualcla_config: Union[str, VisualCLAConfig] = None, torch_dtype=torch.float16,
+                                    default_device=None, device_map=None, load_in_8bit=False, **kwargs):
+        """Separate CLIP / LLaMA checkpoints + a VisualCLA config; the resampler and projection are
+        random-initialised exactly as the reference does before its caller attaches LoRA weights
+        (modeling_visualcla.py:184-261).  Un-merged LoRA loading needs `peft`, which is out of scope."""
+        import json
+        if vision_model_name_or_path is None:
+            raise ValueError("If `vision_model` is not defined as an argument, a `vision_model_name_or_path` has to be defined")
+        if text_model_name_or_path is None:
+            raise ValueError("If `text_model` is not defined as an argument, a `text_model_name_or_path` has to be defined")
+        if isinstance(visualcla_config, str):
+            visualcla_config = VisualCLAConfig.from_pretrained(visualcla_config)
+        with open(os.path.join(text_model_name_or_path, "config.json")) as f:
+            visualcla_config.text_config = json.load(f)
+        with open(os.path.join(vision_model_name_or_path, "config.json")) as f:
+            vc = json.load(f)
+            visualcla_config.vision_config = vc.get("vision_config", vc)
+        sd = {"text_model." + k: v for k, v in cls._read_checkpoint_dir(text_model_name_or_path).items()}
+        sd.update({"vision_model." + k: v for k, v in cls._read_checkpoint_dir(vision_model_name_or_path).items()})
+        r, t = visualcla_config.visual_resampler_config, visualcla_config.text_config
+        g = torch.Generator().manual_seed(0)
+        std = visualcla_config.initializer_range
+        Dr, Ir = r["hidden_size"], r["intermediate_size"]
+        sd["visual_resampler.query_embeddding"] = torch.zeros(1, r["num_query_tokens"], Dr)
+        for i in range(r["num_hidden_layers"]):
+            p = f"visual_resampler.encoder.layer.{i}."
+            for nm, (n, k) in {"crossattention.self.query": (Dr, Dr), "crossattention.self.key": (Dr, Dr),
+                               "crossattention.self.value": (Dr, Dr), "crossattention.output.dense": (Dr, Dr),
+                               "intermediate.dense": (Ir, Dr), "output.dense": (Dr, Ir)}.items():
+                sd[p + nm + ".weight"] = torch.randn(n, k, generator=g) * std
+                sd[p + nm + ".bias"] = torch.zeros(n)
+            for nm in ("crossattention.output.LayerNorm", "output.LayerNorm"):
+                sd[p + nm + ".weight"], sd[p + nm + ".bias"] = torch.ones(Dr), torch.zeros(Dr)
+        sd["image_projection_layer.weight"] = torch.randn(t["hidden_size"], Dr, generator=g) * std
+        sd["image_projection_layer.bias"] = torch.zeros(t["hidden_size"])
+        return cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._dtype
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = False):
+        if mode:
+            raise RuntimeError("the MI355X VisualCLA path is inference-only")
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def _switch_dtype(self, dt: torch.dtype):
+        if dt == self._dtype:
+            return self
+        sd = unpack_state_dict(self._packed, self.config)
+        self._dtype = dt
+        self._packed = pack_state_dict(sd, self.config, self._device, dt)
+        self._ws.clear()
+        self._build_ctx()
+        return self
+
+    def float(self):
+        return self._switch_dtype(torch.float32)
+
+    def half(self):
+        return self._switch_dtype(torch.bfloat16)
+
+    def bfloat16(self):
+        return self._switch_dtype(torch.bfloat16)
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.dtype):
+                self._switch_dtype(_act_dtype(a))
+            elif isinstance(a, (str, torch.device)):
+                dev = torch.device(a)
+                if dev.type != "cuda":
+                    raise _lib.VclaError("VisualCLAModel cannot be moved off the GPU: there is no CPU fallback")
+                if dev != self._device and dev.index is not None:
+                    self._packed = {k: v.to(dev) for k, v in self._packed.items()}
+                    self._device = dev
+                    self._ws.clear()
+                    with torch.cuda.device(dev):
+                        self._build_ctx()
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return unpack_state_dict(self._packed, self.config)
+
+    def get_input_embeddings(self):
+        return _Embedding(self._packed["llama.embed"])
+
+    def get_output_embeddings(self):
+        return _Embedding(self._packed["llama.lm_head"][: self.config.text_config["vocab_size"]])
+
+    def resize_token_embeddings(self, new_num_tokens: Optional[int] = None):
+        V = self.config.text_config["vocab_size"]
+        if new_num_tokens is None or new_num_tokens == V:
+            return self.get_input_embeddings()
+        sd = self.state_dict()
+        for key in ("text_model.model.embed_tokens.weight", "text_model.lm_head.weight"):
+            w = sd[key]
+            new = torch.zeros(new_num_tokens, w.shape[1])
+            n = min(V, new_num_tokens)
+            new[:n] = w[:n]
+            if new_num_tokens > V:
+                new[V:] = torch.randn(new_num_tokens - V, w.shape[1]) * self.config.initializer_range
+            sd[key] = new
+        self.config.text_config["vocab_size"] = new_num_tokens
+        self._packed = pack_state_dict(sd, self.config, self._device, self._dtype)
+        self._ws.clear()
+        self._build_ctx()
+        return self.get_input_embeddings()
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, key: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes) + 512, dtype=torch.uint8, device=self._device)
+            self._ws[key] = t
+        return t
+
+    def _special_ids(self):
+        tk = self.tokenizer
+        if tk is None or not hasattr(tk, "img_start_token_id"):
+            raise ValueError("model.tokenizer with img_start_token_id / img_end_token_id / img_token_id is required "
+                             "(get_model_and_tokenizer_and_processor attaches it)")
+        return tk.img_start_token_id, tk.img_end_token_id, tk.img_token_id
+
+    # ------------------------------------------------------------------ stages
+    def embed_images(self, pixel_values: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """[B, 3, H, W] -> [B, num_query_tokens, text_hidden]: ViT + post-LN + Resampler + projection
+        (the vision half; also what tgwebui's embed_images() computes, .../visualcla/visualcla.py:116-129)."""
+        lib = _lib.load()
+        v, r, t = self.config.vision_config, self.config.visual_resampler_config, self.config.text_config
+        if pixel_values.dim() != 4 or pixel_values.shape[1] != v.get("num_channels", 3) or \
+                pixel_values.shape[2] != v["image_size"] or pixel_values.shape[3] != v["image_size"]:
+            raise ValueError(f"Input image size ({tuple(pixel_values.shape)}) doesn't match model "
+                             f"({v['image_size']}*{v['image_size']}).")
+        B = pixel_values.shape[0]
+        px = pixel_values.to(device=self._device, dtype=self._dtype).contiguous()
+        out = torch.empty(B, r["num_query_tokens"], t["hidden_size"], dtype=self._dtype, device=self._device)
+        nbytes = lib.vcla_vision_workspace_bytes(self._ctx, B)
+        ws = self._buf("vision", nbytes)
+        vit_tap = res_tap = None
+        if taps is not None:
+            N = (v["image_size"] // v["patch_size"]) ** 2 + 1
+            vit_tap = torch.empty(v["num_hidden_layers"] + 1, B, N, v["hidden_size"], dtype=self._dtype, device=self._device)
+            res_tap = torch.empty(r["num_hidden_layers"], B, r["num_query_tokens"], r["hidden_size"], dtype=self._dtype, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(lib.vcla_vision_forward(self._ctx, px.data_ptr(), out.data_ptr(), B, ws.data_ptr(), ws.numel(),
+                                               _lib.ptr(vit_tap), _lib.ptr(res_tap), _lib.stream_ptr()))
+        if taps is not None:
+            for i in range(v["num_hidden_layers"]):
+                taps[f"vit_layer{i}"] = vit_tap[i]
+            taps["vit_post_ln"] = vit_tap[-1]
+            for i in range(r["num_hidden_layers"]):
+                taps[f"resampler_layer{i}"] = res_tap[i]
+            taps["image_embeds"] = out
+        return out
+
+    def _find_image_slots(self, input_ids: torch.Tensor, Q: int, need_img_token: bool) -> torch.Tensor:
+        """Per sample: index of <img> (-1 = no image slot).  Mirrors modeling_visualcla.py:296-302 (forward:
+        also requires an <img_token>) / :362-367 (generate); raises the same ValueError on a malformed slot."""
+        s_id, e_id, t_id = self._special_ids()
+        B, T = input_ids.shape
+        is_start = input_ids == s_id
+        has = is_start.any(dim=1)
+        if need_img_token:
+            has = has & (input_ids == t_id).any(dim=1)
+        p0 = is_start.int().argmax(dim=1)
+        endpos = p0 + Q + 1
+        ok = (endpos < T) & (input_ids.gather(1, endpos.clamp(max=T - 1)[:, None])[:, 0] == e_id)
+        if bool((has & ~ok).any()):
+            raise ValueError(f"Num of patch ({Q}) is not equal to the length of pre-filled image patch tokens.")
+        return torch.where(has, p0, torch.full_like(p0, -1)).to(torch.int32)
+
+    def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], for_generate: bool):
+        """-> (inputs_embeds [B, T', D], attention-mask extension length).  Handles both placements."""
+        lib = _lib.load()
+        t = self.config.text_config
+        B, T = input_ids.shape
+        V, D = t["vocab_size"], t["hidden_size"]
+        if bool(((input_ids < 0) | (input_ids >= V)).any()):
+            raise ValueError("input_ids contain ids outside the vocabulary")
+        Q, img_pos, extra = 0, None, 0
+        ids = input_ids
+        if image_embeds is not None:
+            Q = image_embeds.shape[1]
+            if self.image_at_head:
+                # reference: cat([emb[:, :2], image, emb[:, 2:]]) (modeling_visualcla.py:291) == splice after position 1
+                filler = torch.zeros(B, Q, dtype=ids.dtype, device=ids.device)
+                ids = torch.cat([ids[:, :2], filler, ids[:, 2:]], dim=1)
+                img_pos = torch.full((B,), 1, dtype=torch.int32, device=ids.device)
+                extra = Q
+            else:
+                img_pos = self._find_image_slots(ids, Q, need_img_token=not for_generate)
+        ids = ids.contiguous()
+        Tn = ids.shape[1]
+        out = torch.empty(B, Tn, D, dtype=self._dtype, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(lib.vcla_embed_splice(ids.data_ptr(), self._packed["llama.embed"].data_ptr(),
+                                             _lib.ptr(image_embeds), _lib.ptr(img_pos), out.data_ptr(), B, Tn, Q, D, V,
+                                             _lib.dtype_code(self._dtype), _lib.stream_ptr()))
+        return out, extra
+
+    def _new_cache(self, B: int, ctx_max: int) -> VclaCache:
+        t = self.config.text_config
+        H, d = t["num_attention_heads"], t["hidden_size"] // t["num_attention_heads"]
+        kv = torch.empty(t["num_hidden_layers"], 2, B, H, ctx_max, d, dtype=self._dtype, device=self._device)
+        return VclaCache(kv, 0, ctx_max)
+
+    def _key_mask(self, attention_mask: Optional[torch.Tensor], B: int, T: int, ctx_max: int, extra: int):
+        """int32 [B, ctx_max] or None when nothing is masked (1 = attend)."""
+        if attention_mask is None:
+            return None
+        am = attention_mask.to(self._device)
+        if extra:
+            am = torch.cat([torch.ones(B, extra, dtype=am.dtype, device=am.device), am], dim=1)
+        if am.shape[1] != T:
+            raise ValueError(f"attention_mask length {am.shape[1]} does not match sequence length {T}")
+        if bool(am.bool().all()):
+            return None
+        km = torch.ones(B, ctx_max, dtype=torch.int32, device=self._device)
+        km[:, :T] = am.to(torch.int32)
+        return km
+
+    def _prefill(self, embeds: torch.Tensor, cache: VclaCache, key_mask, all_logits: bool, taps: Optional[dict] = None):
+        lib = _lib.load()
+        t = self.config.text_config
+        B, T, D = embeds.shape
+        V = t["vocab_size"]
+        pos0 = cache.length
+        if pos0 + T > cache.ctx_max:
+            raise ValueError(f"sequence length {pos0 + T} exceeds the KV cache capacity {cache.ctx_max}")
+        logits = torch.empty((B, T, V) if all_logits else (B, V), dtype=torch.float32, device=self._device)
+        nbytes = lib.vcla_llama_workspace_bytes(self._ctx, B, T)
+        ws = self._buf("llama", nbytes)
+        tap = None
+        if taps is not None:
+            tap = torch.empty(t["num_hidden_layers"] + 1, B, T, D, dtype=self._dtype, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(lib.vcla_llama_prefill(self._ctx, embeds.data_ptr(), B, T, pos0, cache.kv.data_ptr(), cache.ctx_max,
+                                              _lib.ptr(key_mask), logits.data_ptr(), int(all_logits), ws.data_ptr(),
+                                              ws.numel(), _lib.ptr(tap), _lib.stream_ptr()))
+        cache.length = pos0 + T
+        if taps is not None:
+            for i in range(t["num_hidden_layers"]):
+                taps[f"llama_layer{i}"] = tap[i]
+            if all_logits:
+                taps["final_norm"] = tap[-1]
+            taps["logits"] = logits
+        return logits
+
+    # ------------------------------------------------------------------ forward (parity entry)
+    def forward(self, input_ids: Optional[torch.LongTensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.LongTensor] = None,
+                past_key_values: Optional[VclaCache] = None, labels: Optional[torch.LongTensor] = None,
+                use_cache: Optional[bool] = None, return_loss: Optional[bool] = None,
+                return_dict: Optional[bool] = None, taps: Optional[dict] = None, **kwargs):
+        """Same contract as the reference forward (modeling_visualcla.py:264-330): logits [B, T, V] (fp32),
+        optional loss, KV cache handle.  `position_ids` is accepted and ignored, as in the reference (:269 vs :321-328)."""
+        from transformers.modeling_outputs import CausalLMOutputWithPast
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+        input_ids = input_ids.to(self._device)
+        B = input_ids.shape[0]
+        img = self.embed_images(pixel_values, taps) if pixel_values is not None else None
+        embeds, extra = self._embed(input_ids, img, for_generate=False)
+        if taps is not None:
+            taps["spliced_embeds"] = embeds
+        T = embeds.shape[1]
+        if labels is not None and extra:
+            labels = torch.cat([labels[:, :1], torch.full((B, extra), -100, dtype=labels.dtype, device=labels.device),
+                                labels[:, 1:]], dim=1)
+        cache = past_key_values
+        if cache is None:
+            cap = T if not use_cache else min(self.config.text_config["max_position_embeddings"], (T + 512 + 63) // 64 * 64)
+            cache = self._new_cache(B, cap)
+        key_mask = self._key_mask(attention_mask, B, cache.length + T, cache.ctx_max, extra) if attention_mask is not None else None
+        logits = self._prefill(embeds, cache, key_mask, all_logits=True, taps=taps)
+        loss = None
+        if labels is not None:
+            lg = logits[:, :-1].reshape(-1, logits.shape[-1])
+            loss = torch.nn.functional.cross_entropy(lg, labels.to(self._device)[:, 1:].reshape(-1), ignore_index=-100)
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache if use_cache else None)
+        if return_dict is False:
+            return tuple(x for x in (loss, logits, out.past_key_values) if x is not None)
+        return out
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ generate
+    def _resolve_generation_config(self, generation_config, kwargs):
+        from transformers import GenerationConfig
+        import copy
+        gc = copy.deepcopy(generation_config or self.generation_config or GenerationConfig())
+        for k in list(kwargs.keys()):
+            if hasattr(gc, k) and k not in ("input_ids", "pixel_values", "attention_mask"):
+                setattr(gc, k, kwargs.pop(k))
+        return gc
+
+    @staticmethod
+    def _eos_list(gc) -> List[int]:
+        e = gc.eos_token_id
+        if e is None:
+            return []
+        return [int(x) for x in e] if isinstance(e, (list, tuple)) else [int(e)]
+
+    def _processors(self, gc, extra_processors):
+        from transformers.generation import logits_process as LP
+        procs = []
+        eos = self._eos_list(gc)
+        if gc.repetition_penalty is not None and gc.repetition_penalty != 1.0:
+            procs.append(LP.RepetitionPenaltyLogitsProcessor(penalty=gc.repetition_penalty))
+        if gc.no_repeat_ngram_size is not None and gc.no_repeat_ngram_size > 0:
+            procs.append(LP.NoRepeatNGramLogitsProcessor(gc.no_repeat_ngram_size))
+        mnt = getattr(gc, "min_new_tokens", None)
+        if mnt and eos:
+            procs.append(LP.MinNewTokensLengthLogitsProcessor(0, mnt, eos, device=str(self._device)))
+        if extra_processors:
+            procs.extend(list(extra_processors))
+        if gc.do_sample:
+            if gc.temperature is not None and gc.temperature != 1.0:
+                procs.append(LP.TemperatureLogitsWarper(gc.temperature))
+            if gc.top_k is not None and gc.top_k != 0:
+                procs.append(LP.TopKLogitsWarper(top_k=gc.top_k))
+            if gc.top_p is not None and gc.top_p < 1.0:
+                procs.append(LP.TopPLogitsWarper(top_p=gc.top_p))
+        return procs
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, pixel_values=None, attention_mask=None, generation_config=None,
+                 logits_processor=None, stopping_criteria=None, prefix_allowed_tokens_fn=None, synced_gpus=False,
+                 use_graph: Optional[bool] = None, **kwargs):
+        """Same contract as the reference generate (modeling_visualcla.py:334-392): returns the NEW tokens only,
+        LongTensor [B, n_new] (what HF generate returns when driven by inputs_embeds).  Greedy decoding without
+        callbacks runs entirely on the device (argmax feeds the next step; optional hipGraph replay)."""
+        lib = _lib.load()
+        if prefix_allowed_tokens_fn is not None:
+            raise ValueError("prefix_allowed_tokens_fn is not supported")
+        gc = self._resolve_generation_config(generation_config, kwargs)
+        if (gc.num_beams or 1) != 1 or (gc.num_return_sequences or 1) != 1:
+            raise ValueError("only num_beams=1, num_return_sequences=1 is supported")
+        t = self.config.text_config
+        input_ids = input_ids.to(self._device)
+        B = input_ids.shape[0]
+        img = self.embed_images(pixel_values) if pixel_values is not None else None
+        embeds, extra = self._embed(input_ids, img, for_generate=True)
+        T = embeds.shape[1]
+        max_pos = t["max_position_embeddings"]
+        if gc.max_new_tokens is not None:
+            n_new = int(gc.max_new_tokens)
+        else:
+            n_new = max(int(gc.max_length or 20), 1)
+        n_new = min(n_new, max_pos - T)
+        if n_new <= 0:
+            raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
+        ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
+        cache = self._new_cache(B, ctx_max)
+        key_mask = self._key_mask(attention_mask, B, T, ctx_max, extra)
+        logits = self._prefill(embeds, cache, key_mask, all_logits=False)
+
+        eos = self._eos_list(gc)
+        pad_id = gc.pad_token_id if gc.pad_token_id is not None else (eos[0] if eos else 0)
+        procs = self._processors(gc, logits_processor)
+        criteria = list(stopping_criteria) if stopping_criteria else []
+        ws = self._buf("llama", lib.vcla_llama_workspace_bytes(self._ctx, B, 1))
+        stream = _lib.stream_ptr()
+        if use_graph is None:
+            use_graph = os.environ.get("VCLA_DECODE_GRAPH", "1") != "0"
+
+        fast = not procs and not criteria and not gc.do_sample
+        if fast:
+            # ---- device-resident greedy loop
+            first = _lib.argmax(logits)
+            out = torch.empty(n_new, B, dtype=torch.int64, device=self._device)
+            out[0] = first
+            done_at = n_new
+            step, chunk = 1, (n_new if not eos else 32)
+            self._pos_dev.zero_()
+            # hipGraph capture is illegal on the legacy default stream: hop onto a side stream for the loop
+            cur_stream = torch.cuda.current_stream(self._device)
+            side = None
+            if use_graph and cur_stream.cuda_stream == 0:
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream(device=self._device)
+                side = self._side_stream
+                side.wait_stream(cur_stream)
+            eos_t = torch.tensor(eos, device=self._device) if eos else None
+            with torch.cuda.device(self._device), torch.cuda.stream(side if side is not None else cur_stream):
+                # position of decode step i's input token = T + *pos_dev; the counter runs 0,1,2,... across chunks so
+                # the captured graph (keyed on buffers + pos0) is reused for the whole generate() call
+                while step < n_new:
+                    k = min(chunk, n_new - step)
+                    _lib.check(lib.vcla_llama_decode_loop(self._ctx, out[step - 1].data_ptr(), B, T, self._pos_dev.data_ptr(), k,
+                                                          cache.kv.data_ptr(), ctx_max, _lib.ptr(key_mask),
+                                                          out[1:].data_ptr(), ws.data_ptr(), ws.numel(), int(use_graph),
+                                                          _lib.stream_ptr()))
+                    step += k
+                    if eos_t is not None and bool(torch.isin(out[:step], eos_t).any(dim=0).all()):
+                        done_at = step
+                        break
+            if side is not None:
+                cur_stream.wait_stream(side)
+            toks = out[:min(step, done_at)].t().contiguous()
+            if eos:
+                is_eos = torch.isin(toks, torch.tensor(eos, device=self._device))
+                after = (is_eos.cumsum(dim=1) - is_eos.int()) > 0
+                toks = torch.where(after, torch.full_like(toks, pad_id), toks)
+                keep = int((~after).any(dim=0).sum())
+                toks = toks[:, :max(keep, 1)]
+            return toks
+
+        # ---- general path: host-driven, one decode step per token; processors / sampling / callbacks in torch
+        generated = torch.empty(B, 0, dtype=torch.int64, device=self._device)
+        done = torch.zeros(B, dtype=torch.bool, device=self._device)
+        eos_t = torch.tensor(eos, device=self._device) if eos else None
+        step_logits = torch.empty(B, t["vocab_size"], dtype=torch.float32, device=self._device)
+        for step in range(n_new):
+            scores = logits
+            for p in procs:
+                scores = p(generated, scores)
+            if gc.do_sample:
+                probs = torch.softmax(scores, dim=-1)
+                nxt = torch.multinomial(probs, num_samples=1)[:, 0]
+            else:
+                nxt = scores.argmax(dim=-1)
+            nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            generated = torch.cat([generated, nxt[:, None]], dim=1)
+            if eos_t is not None:
+                done = done | torch.isin(nxt, eos_t)
+            stop = False
+            for crit in criteria:
+                r = crit(generated, scores)
+                if isinstance(r, torch.Tensor):
+                    done = done | r.to(done.device).bool()
+                elif r:
+                    stop = True
+            if stop or bool(done.all()) or step == n_new - 1:
+                break
+            with torch.cuda.device(self._device):
+                _lib.check(lib.vcla_llama_decode_step(self._ctx, nxt.contiguous().data_ptr(), B, T + step, None, 0,
+                                                      cache.kv.data_ptr(), ctx_max, _lib.ptr(key_mask),
+                                                      step_logits.data_ptr(), None, ws.data_ptr(), ws.numel(), stream))
+            logits = step_logits
+        return generated

@@ -1,0 +1,256 @@
+"""Weight packing: reference state_dict names -> the HBM layout the HIP kernels read.
+
+Layout (see DESIGN.md "Data layout in HBM"):
+  * every Linear weight W [N, K] is stored bf16, K contiguous, rows zero-padded to a multiple of 128
+    (one GEMM workgroup tile) so kernels never bounds-check the weight operand;
+  * q/k/v projections are concatenated row-wise into one [3D, D] matrix (one GEMM instead of three);
+  * the resampler's key/value projections are concatenated into [2D, D];
+  * LLaMA gate/up projections are interleaved in blocks of 16 rows (16 gate, 16 up, ...) so the SwiGLU
+    product is formed inside the GEMM epilogue from two accumulator tiles of the same lane;
+  * the patch-embedding conv weight [D, 3, P, P] is flattened to [D, 3*P*P] and zero-padded in K to a
+    multiple of 64 (588 -> 640) to match the im2col operand;
+  * biases, norm gains, class/position embeddings and the RoPE cos/sin tables are fp32.
+
+State-dict key names follow the reference (`text_model.` / `vision_model.` / `visual_resampler.` /
+`image_projection_layer.`; scripts/merge_llama_with_visualcla_lora.py:95-96, models/visualcla/modeling_visualcla.py:172-179).
+Both CLIP layouts are accepted: `vision_model.vision_model.*` (transformers 4.x, what the reference saves)
+and the flat `vision_model.*` of transformers 5.x.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict
+
+import torch
+
+
+def pad_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _pack_w(w: torch.Tensor, device) -> torch.Tensor:
+    """[N, K] -> bf16 [pad128(N), K] on device."""
+    n, k = w.shape
+    out = torch.zeros(pad_to(n, 128), k, dtype=torch.bfloat16, device=device)
+    out[:n] = w.to(device=device, dtype=torch.bfloat16)
+    return out
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I, K] x2 -> [2I, K] with rows (16 gate, 16 up) repeating."""
+    i, k = gate.shape
+    assert i % 16 == 0, "intermediate size must be a multiple of 16"
+    return torch.stack([gate.reshape(i // 16, 16, k), up.reshape(i // 16, 16, k)], dim=1).reshape(2 * i, k)
+
+
+def rope_tables(max_pos: int, head_dim: int, theta: float):
+    """fp32 cos/sin [max_pos, head_dim/2], computed exactly as hf:llama/modeling_llama.py:98-127 does (CPU, fp32)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+def pack_state_dict(sd: Dict[str, torch.Tensor], cfg, device, act_dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+    """cfg: visualcla.VisualCLAConfig (dict sub-configs).  Returns {engine tensor name: device tensor}."""
+    v, r, t = cfg.vision_config, cfg.visual_resampler_config, cfg.text_config
+    out: Dict[str, torch.Tensor] = {}
+
+    vp = "vision_model.vision_model." if any(k.startswith("vision_model.vision_model.") for k in sd) else "vision_model."
+
+    def g(name):
+        if name not in sd:
+            raise KeyError(f"state_dict is missing '{name}'")
+        return sd[name]
+
+    D = v["hidden_size"]
+    pw = g(vp + "embeddings.patch_embedding.weight").reshape(D, -1).float()
+    kpad = pad_to(pw.shape[1], 64)
+    pw = torch.nn.functional.pad(pw, (0, kpad - pw.shape[1]))
+    out["vit.patch_w"] = _pack_w(pw, device)
+    out["vit.cls"] = _f32(g(vp + "embeddings.class_embedding").reshape(-1), device)
+    out["vit.pos"] = _f32(g(vp + "embeddings.position_embedding.weight"), device)
+    out["vit.pre_ln.g"] = _f32(g(vp + "pre_layrnorm.weight"), device)
+    out["vit.pre_ln.b"] = _f32(g(vp + "pre_layrnorm.bias"), device)
+    out["vit.post_ln.g"] = _f32(g(vp + "post_layernorm.weight"), device)
+    out["vit.post_ln.b"] = _f32(g(vp + "post_layernorm.bias"), device)
+    for i in range(v["num_hidden_layers"]):
+        s, d = f"{vp}encoder.layers.{i}.", f"vit.l{i}."
+        out[d + "ln1.g"] = _f32(g(s + "layer_norm1.weight"), device)
+        out[d + "ln1.b"] = _f32(g(s + "layer_norm1.bias"), device)
+        out[d + "wqkv"] = _pack_w(torch.cat([g(s + f"self_attn.{n}_proj.weight") for n in "qkv"], 0), device)
+        out[d + "bqkv"] = _f32(torch.cat([g(s + f"self_attn.{n}_proj.bias") for n in "qkv"], 0), device)
+        out[d + "wo"] = _pack_w(g(s + "self_attn.out_proj.weight"), device)
+        out[d + "bo"] = _f32(g(s + "self_attn.out_proj.bias"), device)
+        out[d + "ln2.g"] = _f32(g(s + "layer_norm2.weight"), device)
+        out[d + "ln2.b"] = _f32(g(s + "layer_norm2.bias"), device)
+        out[d + "w1"] = _pack_w(g(s + "mlp.fc1.weight"), device)
+        out[d + "b1"] = _f32(g(s + "mlp.fc1.bias"), device)
+        out[d + "w2"] = _pack_w(g(s + "mlp.fc2.weight"), device)
+        out[d + "b2"] = _f32(g(s + "mlp.fc2.bias"), device)
+
+    rp = "visual_resampler."
+    # bf16-round the learned queries once, like every other weight, then hold them in the activation dtype
+    out["res.query"] = g(rp + "query_embeddding").reshape(r["num_query_tokens"], r["hidden_size"]).to(
+        device=device, dtype=torch.bfloat16).to(act_dtype).contiguous()
+    for i in range(r["num_hidden_layers"]):
+        s, d = f"{rp}encoder.layer.{i}.", f"res.l{i}."
+        out[d + "wq"] = _pack_w(g(s + "crossattention.self.query.weight"), device)
+        out[d + "bq"] = _f32(g(s + "crossattention.self.query.bias"), device)
+        out[d + "wkv"] = _pack_w(torch.cat([g(s + "crossattention.self.key.weight"),
+                                            g(s + "crossattention.self.value.weight")], 0), device)
+        out[d + "bkv"] = _f32(torch.cat([g(s + "crossattention.self.key.bias"),
+                                         g(s + "crossattention.self.value.bias")], 0), device)
+        out[d + "wo"] = _pack_w(g(s + "crossattention.output.dense.weight"), device)
+        out[d + "bo"] = _f32(g(s + "crossattention.output.dense.bias"), device)
+        out[d + "ln1.g"] = _f32(g(s + "crossattention.output.LayerNorm.weight"), device)
+        out[d + "ln1.b"] = _f32(g(s + "crossattention.output.LayerNorm.bias"), device)
+        out[d + "w1"] = _pack_w(g(s + "intermediate.dense.weight"), device)
+        out[d + "b1"] = _f32(g(s + "intermediate.dense.bias"), device)
+        out[d + "w2"] = _pack_w(g(s + "output.dense.weight"), device)
+        out[d + "b2"] = _f32(g(s + "output.dense.bias"), device)
+        out[d + "ln2.g"] = _f32(g(s + "output.LayerNorm.weight"), device)
+        out[d + "ln2.b"] = _f32(g(s + "output.LayerNorm.bias"), device)
+    out["proj.w"] = _pack_w(g("image_projection_layer.weight"), device)
+    out["proj.b"] = _f32(g("image_projection_layer.bias"), device)
+
+    tp = "text_model."
+    out["llama.embed"] = g(tp + "model.embed_tokens.weight").to(device=device, dtype=torch.bfloat16).contiguous()
+    for i in range(t["num_hidden_layers"]):
+        s, d = f"{tp}model.layers.{i}.", f"llama.l{i}."
+        out[d + "ln1.g"] = _f32(g(s + "input_layernorm.weight"), device)
+        out[d + "ln2.g"] = _f32(g(s + "post_attention_layernorm.weight"), device)
+        out[d + "wqkv"] = _pack_w(torch.cat([g(s + f"self_attn.{n}_proj.weight") for n in "qkv"], 0), device)
+        out[d + "wo"] = _pack_w(g(s + "self_attn.o_proj.weight"), device)
+        out[d + "wgu"] = _pack_w(interleave_gate_up(g(s + "mlp.gate_proj.weight"), g(s + "mlp.up_proj.weight")), device)
+        out[d + "wd"] = _pack_w(g(s + "mlp.down_proj.weight"), device)
+    out["llama.norm.g"] = _f32(g(tp + "model.norm.weight"), device)
+    out["llama.lm_head"] = _pack_w(g(tp + "lm_head.weight"), device)
+    hd = t["hidden_size"] // t["num_attention_heads"]
+    theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
+    cos, sin = rope_tables(t["max_position_embeddings"], hd, theta)
+    out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
+    return out
+
+
+def random_packed(cfg, device, act_dtype: torch.dtype, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights generated directly in the packed device layout (benchmarks: there are no
+    checkpoints to load, and a 7B state_dict does not need to round-trip through the host).
+    Same distributions as the oracle's make_weights (N(0, .02) matrices, gains 1 + N(0, .1))."""
+    v, r, t = cfg.vision_config, cfg.visual_resampler_config, cfg.text_config
+    gen = torch.Generator(device=device).manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+
+    def w(n, k, k_real=None):
+        m = torch.zeros(pad_to(n, 128), k, dtype=torch.bfloat16, device=device)
+        kk = k_real or k
+        m[:n, :kk] = (torch.randn(n, kk, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        return m
+
+    def vec(n, mean=0.0, std=0.02):
+        x = torch.randn(n, generator=gen, device=device, dtype=torch.float32) * std + mean
+        return x.to(torch.bfloat16).float()
+
+    D, I = v["hidden_size"], v["intermediate_size"]
+    kreal = v.get("num_channels", 3) * v["patch_size"] ** 2
+    npos = (v["image_size"] // v["patch_size"]) ** 2 + 1
+    out["vit.patch_w"] = w(D, pad_to(kreal, 64), kreal)
+    out["vit.cls"] = vec(D)
+    out["vit.pos"] = vec(npos * D).view(npos, D)
+    for n in ("pre_ln", "post_ln"):
+        out[f"vit.{n}.g"], out[f"vit.{n}.b"] = vec(D, 1.0, 0.1), vec(D)
+    for i in range(v["num_hidden_layers"]):
+        d = f"vit.l{i}."
+        out[d + "ln1.g"], out[d + "ln1.b"] = vec(D, 1.0, 0.1), vec(D)
+        out[d + "wqkv"], out[d + "bqkv"] = w(3 * D, D), vec(3 * D)
+        out[d + "wo"], out[d + "bo"] = w(D, D), vec(D)
+        out[d + "ln2.g"], out[d + "ln2.b"] = vec(D, 1.0, 0.1), vec(D)
+        out[d + "w1"], out[d + "b1"] = w(I, D), vec(I)
+        out[d + "w2"], out[d + "b2"] = w(D, I), vec(D)
+    Dr, Ir, Q = r["hidden_size"], r["intermediate_size"], r["num_query_tokens"]
+    out["res.query"] = vec(Q * Dr).view(Q, Dr).to(act_dtype)
+    for i in range(r["num_hidden_layers"]):
+        d = f"res.l{i}."
+        out[d + "wq"], out[d + "bq"] = w(Dr, Dr), vec(Dr)
+        out[d + "wkv"], out[d + "bkv"] = w(2 * Dr, Dr), vec(2 * Dr)
+        out[d + "wo"], out[d + "bo"] = w(Dr, Dr), vec(Dr)
+        out[d + "ln1.g"], out[d + "ln1.b"] = vec(Dr, 1.0, 0.1), vec(Dr)
+        out[d + "w1"], out[d + "b1"] = w(Ir, Dr), vec(Ir)
+        out[d + "w2"], out[d + "b2"] = w(Dr, Ir), vec(Dr)
+        out[d + "ln2.g"], out[d + "ln2.b"] = vec(Dr, 1.0, 0.1), vec(Dr)
+    Dt, It, V = t["hidden_size"], t["intermediate_size"], t["vocab_size"]
+    out["proj.w"], out["proj.b"] = w(Dt, Dr), vec(Dt)
+    out["llama.embed"] = (torch.randn(V, Dt, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    for i in range(t["num_hidden_layers"]):
+        d = f"llama.l{i}."
+        out[d + "ln1.g"], out[d + "ln2.g"] = vec(Dt, 1.0, 0.1), vec(Dt, 1.0, 0.1)
+        out[d + "wqkv"], out[d + "wo"] = w(3 * Dt, Dt), w(Dt, Dt)
+        out[d + "wgu"], out[d + "wd"] = w(2 * It, Dt), w(Dt, It)
+    out["llama.norm.g"] = vec(Dt, 1.0, 0.1)
+    out["llama.lm_head"] = w(V, Dt)
+    hd = Dt // t["num_attention_heads"]
+    theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
+    cos, sin = rope_tables(t["max_position_embeddings"], hd, theta)
+    out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
+    return out
+
+
+def unpack_state_dict(packed: Dict[str, torch.Tensor], cfg) -> Dict[str, torch.Tensor]:
+    """Inverse of pack_state_dict (CPU fp32, reference names): lets the CPU oracle run on weights that were
+    generated in packed form, and backs `VisualCLAModel.state_dict()`."""
+    v, r, t = cfg.vision_config, cfg.visual_resampler_config, cfg.text_config
+    sd: Dict[str, torch.Tensor] = {}
+    c = lambda x: x.detach().float().cpu()
+    D = v["hidden_size"]
+    C_, P = v.get("num_channels", 3), v["patch_size"]
+    vp = "vision_model.vision_model."
+    sd[vp + "embeddings.patch_embedding.weight"] = c(packed["vit.patch_w"][:D, :C_ * P * P]).reshape(D, C_, P, P)
+    sd[vp + "embeddings.class_embedding"] = c(packed["vit.cls"])
+    sd[vp + "embeddings.position_embedding.weight"] = c(packed["vit.pos"])
+    for a, b in (("pre_layrnorm", "pre_ln"), ("post_layernorm", "post_ln")):
+        sd[vp + a + ".weight"], sd[vp + a + ".bias"] = c(packed[f"vit.{b}.g"]), c(packed[f"vit.{b}.b"])
+    I = v["intermediate_size"]
+    for i in range(v["num_hidden_layers"]):
+        s, d = f"{vp}encoder.layers.{i}.", f"vit.l{i}."
+        wqkv, bqkv = c(packed[d + "wqkv"][:3 * D]), c(packed[d + "bqkv"])
+        for j, n in enumerate("qkv"):
+            sd[s + f"self_attn.{n}_proj.weight"] = wqkv[j * D:(j + 1) * D]
+            sd[s + f"self_attn.{n}_proj.bias"] = bqkv[j * D:(j + 1) * D]
+        sd[s + "self_attn.out_proj.weight"], sd[s + "self_attn.out_proj.bias"] = c(packed[d + "wo"][:D]), c(packed[d + "bo"])
+        sd[s + "layer_norm1.weight"], sd[s + "layer_norm1.bias"] = c(packed[d + "ln1.g"]), c(packed[d + "ln1.b"])
+        sd[s + "layer_norm2.weight"], sd[s + "layer_norm2.bias"] = c(packed[d + "ln2.g"]), c(packed[d + "ln2.b"])
+        sd[s + "mlp.fc1.weight"], sd[s + "mlp.fc1.bias"] = c(packed[d + "w1"][:I]), c(packed[d + "b1"])
+        sd[s + "mlp.fc2.weight"], sd[s + "mlp.fc2.bias"] = c(packed[d + "w2"][:D]), c(packed[d + "b2"])
+    rp = "visual_resampler."
+    Dr, Ir = r["hidden_size"], r["intermediate_size"]
+    sd[rp + "query_embeddding"] = c(packed["res.query"]).reshape(1, r["num_query_tokens"], Dr)
+    for i in range(r["num_hidden_layers"]):
+        s, d = f"{rp}encoder.layer.{i}.", f"res.l{i}."
+        sd[s + "crossattention.self.query.weight"], sd[s + "crossattention.self.query.bias"] = c(packed[d + "wq"][:Dr]), c(packed[d + "bq"])
+        wkv, bkv = c(packed[d + "wkv"][:2 * Dr]), c(packed[d + "bkv"])
+        sd[s + "crossattention.self.key.weight"], sd[s + "crossattention.self.value.weight"] = wkv[:Dr], wkv[Dr:]
+        sd[s + "crossattention.self.key.bias"], sd[s + "crossattention.self.value.bias"] = bkv[:Dr], bkv[Dr:]
+        sd[s + "crossattention.output.dense.weight"], sd[s + "crossattention.output.dense.bias"] = c(packed[d + "wo"][:Dr]), c(packed[d + "bo"])
+        sd[s + "crossattention.output.LayerNorm.weight"], sd[s + "crossattention.output.LayerNorm.bias"] = c(packed[d + "ln1.g"]), c(packed[d + "ln1.b"])
+        sd[s + "intermediate.dense.weight"], sd[s + "intermediate.dense.bias"] = c(packed[d + "w1"][:Ir]), c(packed[d + "b1"])
+        sd[s + "output.dense.weight"], sd[s + "output.dense.bias"] = c(packed[d + "w2"][:Dr]), c(packed[d + "b2"])
+        sd[s + "output.LayerNorm.weight"], sd[s + "output.LayerNorm.bias"] = c(packed[d + "ln2.g"]), c(packed[d + "ln2.b"])
+    Dt, It, V = t["hidden_size"], t["intermediate_size"], t["vocab_size"]
+    sd["image_projection_layer.weight"], sd["image_projection_layer.bias"] = c(packed["proj.w"][:Dt]), c(packed["proj.b"])
+    tp = "text_model."
+    sd[tp + "model.embed_tokens.weight"] = c(packed["llama.embed"])
+    for i in range(t["num_hidden_layers"]):
+        s, d = f"{tp}model.layers.{i}.", f"llama.l{i}."
+        wqkv = c(packed[d + "wqkv"][:3 * Dt])
+        for j, n in enumerate("qkv"):
+            sd[s + f"self_attn.{n}_proj.weight"] = wqkv[j * Dt:(j + 1) * Dt]
+        sd[s + "self_attn.o_proj.weight"] = c(packed[d + "wo"][:Dt])
+        gu = c(packed[d + "wgu"][:2 * It]).reshape(It // 16, 2, 16, Dt)
+        sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"] = gu[:, 0].reshape(It, Dt), gu[:, 1].reshape(It, Dt)
+        sd[s + "mlp.down_proj.weight"] = c(packed[d + "wd"][:Dt])
+        sd[s + "input_layernorm.weight"], sd[s + "post_attention_layernorm.weight"] = c(packed[d + "ln1.g"]), c(packed[d + "ln2.g"])
+    sd[tp + "model.norm.weight"] = c(packed["llama.norm.g"])
+    sd[tp + "lm_head.weight"] = c(packed["llama.lm_head"][:V])
+    return sd
