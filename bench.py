@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=4, help="decode tokens in the bounded CPU sample")
+    ap.add_argument("--cpu-tokens", type=int, default=3, help="decode tokens in the bounded CPU sample")
     return ap.parse_args()
 
 
@@ -92,7 +92,9 @@ def cpu_baseline(model, cfg_o, prompt_len: int, new_tokens: int, sample_tokens: 
     sample of the same request: 1 image through the vision stack + prefill of the T=128 prompt + `sample_tokens` decode
     steps; tokens/s is scaled to the full 128-token request as 128 / (t_vision + t_prefill + 128 * t_step)."""
     from oracle import visualcla_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one NUMA domain's worth of threads: torch's CPU kernels collapse when spread over all 256 SMT threads of the
+    # GPU box's 2-socket host (measured: 28 s/token at 256 threads)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     t0 = time.time()
     W = model.state_dict()                      # bf16-rounded values, fp32 on the host (~27 GB)
     t_unpack = time.time() - t0

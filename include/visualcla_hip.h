@@ -34,6 +34,8 @@
  *                           hf:llama/modeling_llama.py:191-214; modeling_visual_resampler.py:213-253
  *   vcla_embed_splice       embed_tokens + image splice modeling_visualcla.py:280,292-305 / :346,358-370
  *   vcla_rope_kv_append     apply_rotary_pos_emb + cache update hf:llama/modeling_llama.py:130-160,255-259
+ *   vcla_attn_decode_fused  the decode-step instance of LlamaAttention.forward hf:llama/modeling_llama.py:217-281
+ *                           (RoPE + DynamicCache.update + eager attention) in one launch
  *   vcla_argmax             greedy token selection hf:generation/utils.py (argmax over fp32 logits)
  *   vcla_vision_forward     modeling_visualcla.py:283-288 / :349-354 (and tgwebui embed_images,
  *                           scripts/inference/text_generation_webui/visualcla/visualcla.py:116-129)
@@ -107,6 +109,10 @@ typedef struct vcla_gemm_args {
        (m % c_group_rows) + c_row_offset of C (c_group_rows == 0: identity)                    */
     int c_group_rows, c_group_stride, c_row_offset;
     int force_kernel;     /* 0 auto; 1 MFMA tile kernel; 2 row-streaming GEMV kernel; 3 fp32 tile */
+    /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
+       kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
+    const float* norm_gamma; /* [K] or NULL */
+    float norm_eps;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */
@@ -152,6 +158,13 @@ int vcla_embed_splice(const int64_t* ids, const void* table, const void* image_e
 int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
                         int B, int T, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev, int dtype,
                         void* stream);
+
+/* Fused decode-step attention for every (sequence, head): RoPE on q and the new k of the fused qkv row [B, 3*H*d],
+   append k / v to the cache at position pos0 + (pos_dev ? *pos_dev : 0), softmax(scale q K^T) V over keys 0..pos.
+   out [B, H*d].  key_mask [B, key_mask_ld] optional. */
+int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
+                           void* out, int B, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev,
+                           const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, void* stream);
 
 /* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
 int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);

@@ -72,11 +72,12 @@ def test_layernorm_strided_rows(lib):
     # last-token selection in prefill: rows picked with a stride larger than cols
     x = torch.randn(6, 4, 256)
     gamma, beta = torch.randn(256), torch.randn(256)
-    xd = x.to(DEV)
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)   # keep device tensors alive across the call
     view = xd[:, 3, :]                       # stride 1024
     out = torch.empty(6, 256, device=DEV)
-    lib.check(lib.load().vcla_layernorm(view.data_ptr(), view.stride(0), gamma.to(DEV).data_ptr(), beta.to(DEV).data_ptr(),
+    lib.check(lib.load().vcla_layernorm(view.data_ptr(), view.stride(0), gd.data_ptr(), bd.data_ptr(),
                                         out.data_ptr(), 256, 6, 256, 1e-5, 0, lib.stream_ptr()))
+    torch.cuda.synchronize()
     _cmp("layernorm[strided]", out, O.layer_norm(x[:, 3, :], gamma, beta, 1e-5), atol=2e-5)
 
 
@@ -262,8 +263,10 @@ def test_embed_splice(lib, dtype):
             ref[b, pos[b] + 1:pos[b] + 1 + Q] = img[b]
     out = torch.empty(B, T, D, dtype=dtype, device=DEV)
     L = lib.load()
-    lib.check(L.vcla_embed_splice(ids.to(DEV).data_ptr(), table.to(DEV, torch.bfloat16).data_ptr(), img.to(DEV, dtype).data_ptr(),
-                                  pos.to(DEV).data_ptr(), out.data_ptr(), B, T, Q, D, V, lib.dtype_code(dtype), lib.stream_ptr()))
+    ids_d, tab_d, img_d, pos_d = ids.to(DEV), table.to(DEV, torch.bfloat16), img.to(DEV, dtype), pos.to(DEV)
+    lib.check(L.vcla_embed_splice(ids_d.data_ptr(), tab_d.data_ptr(), img_d.data_ptr(), pos_d.data_ptr(), out.data_ptr(),
+                                  B, T, Q, D, V, lib.dtype_code(dtype), lib.stream_ptr()))
+    torch.cuda.synchronize()
     _cmp(f"embed_splice[{dtype}]", out, ref, atol=0.0)       # pure data movement: bit exact
 
 
@@ -285,8 +288,10 @@ def test_rope_kv_append(lib, dtype):
     vc = torch.zeros(B, H, ctx, d, dtype=dtype, device=DEV)
     pos_dev = torch.tensor([1], dtype=torch.int32, device=DEV)
     L = lib.load()
-    lib.check(L.vcla_rope_kv_append(buf.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.to(DEV).data_ptr(), sin.to(DEV).data_ptr(),
+    cos_d, sin_d = cos.to(DEV), sin.to(DEV)
+    lib.check(L.vcla_rope_kv_append(buf.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(),
                                     B, T, H, d, ctx, pos0 - 1, pos_dev.data_ptr(), lib.dtype_code(dtype), lib.stream_ptr()))
+    torch.cuda.synchronize()
     tol = 1e-6 if dtype == torch.float32 else 2e-2
     _cmp(f"rope_q[{dtype}]", buf.view(B, T, 3, H, d)[:, :, 0].transpose(1, 2), qr, atol=tol)
     _cmp(f"rope_k_cache[{dtype}]", kc[:, :, pos0:pos0 + T], kr, atol=tol)
@@ -317,7 +322,8 @@ def test_patch_embed_pipeline(lib, dtype):
     L = lib.load()
     np_ = cfg.num_patches
     patches = torch.empty(2 * np_, kpad, dtype=dtype, device=DEV)
-    lib.check(L.vcla_im2col(px.to(DEV, dtype).contiguous().data_ptr(), patches.data_ptr(), 2, 3, cfg.image_size, cfg.image_size,
+    px_d = px.to(DEV, dtype).contiguous()
+    lib.check(L.vcla_im2col(px_d.data_ptr(), patches.data_ptr(), 2, 3, cfg.image_size, cfg.image_size,
                             P, kpad, lib.dtype_code(dtype), lib.stream_ptr()))
     wp = torch.nn.functional.pad(W[p + "embeddings.patch_embedding.weight"].reshape(D, kreal), (0, kpad - kreal))
     pe = lib.gemm(patches, _pack(wp), D)
@@ -327,3 +333,105 @@ def test_patch_embed_pipeline(lib, dtype):
     lib.check(L.vcla_vit_assemble(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), gm.data_ptr(), bt.data_ptr(), out.data_ptr(),
                                   2, np_, D, cfg.layer_norm_eps, lib.dtype_code(dtype), lib.stream_ptr()))
     _cmp(f"patch_embed[{dtype}]", out.view(2, np_ + 1, D), ref, atol=1e-4 if dtype == torch.float32 else 6e-2)
+
+
+# ------------------------------------------------------------------ fused RMSNorm + GEMV (decode path)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,epi", [(1, 4096, 512, 0), (3, 320, 256, 0), (8, 2048, 1408, 3), (1, 12288, 4096, 0), (2, 22016, 4096, 3)])
+def test_gemv_fused_rmsnorm(lib, dtype, M, N, K, epi):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bf16r(torch.randn(M, K, generator=g) * 1.3)
+    gamma = bf16r(1 + 0.1 * torch.randn(K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.03)
+    res = bf16r(torch.randn(M, N // 2 if epi == 3 else N, generator=g))
+    h = O.llama_rmsnorm(x, gamma, 1e-6)                      # fp32 reference of the norm
+    ref = _gemm_ref(h, w, None, epi, res)
+    got = lib.gemm(x.to(DEV, dtype), _pack(w), N, residual=res.to(DEV, dtype), epilogue=epi, norm_gamma=gamma.to(DEV),
+                   norm_eps=1e-6)
+    _cmp(f"gemv_fused_norm[{dtype},{M}x{N}x{K},epi{epi}]", got, ref, atol=2e-4 if dtype == torch.float32 else 3e-3,
+         rtol=1e-5 if dtype == torch.float32 else 8e-3)
+
+
+# ------------------------------------------------------------------ fused decode attention (RoPE + append + attend)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,d,pos", [(2, 4, 128, 37), (1, 3, 64, 200), (3, 2, 32, 5), (1, 2, 128, 0), (2, 2, 128, 700)])
+def test_attn_decode_fused(lib, dtype, B, H, d, pos):
+    from visualcla.weights import rope_tables
+    ctx = max(64, (pos + 64) // 64 * 64)
+    g = torch.Generator().manual_seed(B + H + d + pos)
+    qkv = bf16r(torch.randn(B, 3, H, d, generator=g))
+    kc = bf16r(torch.randn(B, H, ctx, d, generator=g))
+    vc = bf16r(torch.randn(B, H, ctx, d, generator=g))
+    km = torch.ones(B, ctx, dtype=torch.int32)
+    if pos > 3:
+        km[0, 1:3] = 0
+    cos, sin = rope_tables(1024, d, 10000.0)
+    c, s = O.llama_rope_tables(torch.tensor([pos]), d, 10000.0, torch.float32)
+    rnd = (lambda t: t) if dtype == torch.float32 else bf16r
+    c, s = rnd(c), rnd(s)
+    q = rnd(O.apply_rope(qkv[:, 0][:, :, None, :], c, s))          # [B,H,1,d]
+    kn = rnd(O.apply_rope(qkv[:, 1][:, :, None, :], c, s))
+    K = torch.cat([kc[:, :, :pos], kn], dim=2)
+    V = torch.cat([vc[:, :, :pos], qkv[:, 2][:, :, None, :]], dim=2)
+    ref = _attn_ref(q, K, V, 1 / math.sqrt(d), True, km)
+    kc_d, vc_d = kc.to(DEV, dtype), vc.to(DEV, dtype)
+    qkv_d = qkv.reshape(B, 3 * H * d).to(DEV, dtype).contiguous()
+    out = torch.empty(B, H * d, dtype=dtype, device=DEV)
+    pos_dev = torch.tensor([2], dtype=torch.int32, device=DEV)
+    cos_d, sin_d, km_d = cos.to(DEV), sin.to(DEV), km.to(DEV)
+    L = lib.load()
+    lib.check(L.vcla_attn_decode_fused(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(),
+                                       out.data_ptr(), B, H, d, ctx, pos - 2, pos_dev.data_ptr(), km_d.data_ptr(), ctx,
+                                       1 / math.sqrt(d), lib.dtype_code(dtype), lib.stream_ptr()))
+    torch.cuda.synchronize()
+    _cmp(f"attn_decode_fused[{dtype},B{B}H{H}d{d}pos{pos}]", out.view(B, 1, H * d), ref, atol=3e-5 if dtype == torch.float32 else 1.5e-2)
+    # the cache must now hold the roped key / raw value at `pos`, everything else untouched
+    _cmp("decode_k_append", kc_d[:, :, pos], kn[:, :, 0], atol=1e-6 if dtype == torch.float32 else 2e-2)
+    _cmp("decode_v_append", vc_d[:, :, pos], qkv[:, 2], atol=0.0)
+    assert torch.equal(kc_d[:, :, :pos].float().cpu(), kc[:, :, :pos]) and torch.equal(kc_d[:, :, pos + 1:].float().cpu(), kc[:, :, pos + 1:])
+
+
+# ------------------------------------------------------------------ MFMA flash attention (bf16)
+@pytest.mark.parametrize("B,H,Tq,Tk,D,causal", [
+    (2, 3, 257, 257, 64, False), (1, 2, 64, 321, 64, False), (2, 4, 48, 48, 128, True), (1, 2, 130, 130, 128, True),
+    (1, 2, 128, 128, 128, True), (2, 2, 100, 228, 128, True), (1, 1, 16, 16, 64, False), (1, 2, 577, 577, 64, False),
+    (1, 1, 300, 1000, 128, True),
+])
+def test_attention_mfma(lib, B, H, Tq, Tk, D, causal):
+    g = torch.Generator().manual_seed(B * 3 + H + Tq + Tk + D)
+    q, k, v = (bf16r(torch.randn(B, H, T, D, generator=g)) for T in (Tq, Tk, Tk))
+    ref = _attn_ref(q, k, v, 1 / math.sqrt(D), causal, None)
+    dt = torch.bfloat16
+    got = lib.attention(q.to(DEV, dt), k.to(DEV, dt), v.to(DEV, dt), 1 / math.sqrt(D), causal=causal, force_kernel=2)
+    gen = lib.attention(q.to(DEV, dt), k.to(DEV, dt), v.to(DEV, dt), 1 / math.sqrt(D), causal=causal, force_kernel=1)
+    _cmp(f"attn_mfma[B{B}H{H}Tq{Tq}Tk{Tk}D{D}c{int(causal)}]", got, ref, atol=1.5e-2)
+    _cmp(f"attn_mfma_vs_generic[Tq{Tq}Tk{Tk}D{D}]", got, gen.float(), atol=1.6e-2)
+
+
+def test_attention_mfma_mask_and_strides(lib):
+    # fused-qkv strides + left padding, as LLaMA prefill with a padded batch would issue it
+    B, H, T, D = 2, 4, 70, 128
+    g = torch.Generator().manual_seed(21)
+    qkv = bf16r(torch.randn(B, T, 3 * H * D, generator=g))
+    km = torch.ones(B, T, dtype=torch.int32)
+    km[1, :9] = 0
+    q, k, v = (qkv[..., i * H * D:(i + 1) * H * D].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    ref = _attn_ref(q, k, v, D ** -0.5, True, km)
+    qd = qkv.to(DEV, torch.bfloat16)
+    qv, kv, vv = (qd[..., i * H * D:(i + 1) * H * D].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    got = lib.attention(qv, kv, vv, D ** -0.5, causal=True, key_mask=km.to(DEV), force_kernel=2)
+    valid = torch.ones(B, T, dtype=torch.bool)
+    valid[1, :9] = False
+    assert torch.isfinite(got).all()
+    _cmp("attn_mfma_mask_strided", got[valid.to(DEV)], ref[valid], atol=1.5e-2)
+
+
+def test_attention_mfma_softmax_rescale_branch(lib):
+    """online-softmax hazard: a key far above the running max in a LATE tile forces the rescale of O and l."""
+    B, H, T, D = 1, 1, 256, 64
+    g = torch.Generator().manual_seed(33)
+    q, k, v = (bf16r(torch.randn(B, H, T, D, generator=g)) for _ in range(3))
+    k[0, 0, 200] = bf16r(q[0, 0, 17] * 4.0)          # spike: q17 . k200 >> everything before it
+    ref = _attn_ref(q, k, v, D ** -0.5, False, None)
+    got = lib.attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), v.to(DEV, torch.bfloat16), D ** -0.5, force_kernel=2)
+    _cmp("attn_mfma_rescale", got, ref, atol=1.5e-2)

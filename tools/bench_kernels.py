@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks on the VisualCLA-7B shapes (run on the GPU box): GEMM TF/s against the 2.5 PF bf16 MFMA
+peak, GEMV / decode-attention GB/s against the 8 TB/s HBM peak, attention TF/s.  Random data (never zero-filled)."""
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
+import torch
+from visualcla import _lib
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16)
+
+
+def packw(n, k):
+    w = torch.zeros((n + 127) // 128 * 128, k, dtype=torch.bfloat16, device=DEV)
+    w[:n] = rnd(n, k, scale=0.02)
+    return w
+
+
+def bench_gemm(tag, M, N, K, epi=0, fk=1):
+    a, w = rnd(M, K), packw(N, K)
+    out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+    t = timeit(lambda: _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk))
+    tf = 2.0 * M * N * K / t / 1e12
+    print(f"gemm  {tag:28s} M={M:6d} N={N:6d} K={K:6d} epi={epi}  {t*1e6:9.1f} us  {tf:8.1f} TF/s  ({tf/2500*100:5.1f}% of bf16 MFMA peak)")
+
+
+def bench_gemv(tag, M, N, K, epi=0, fused_norm=False):
+    a, w = rnd(M, K), packw(N, K)
+    gamma = torch.ones(K, device=DEV) if fused_norm else None
+    out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+    t = timeit(lambda: _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=2, norm_gamma=gamma, norm_eps=1e-6), reps=50)
+    gbs = N * K * 2 / t / 1e9
+    print(f"gemv  {tag:28s} M={M:6d} N={N:6d} K={K:6d} epi={epi}  {t*1e6:9.1f} us  {gbs:8.1f} GB/s  ({gbs/8000*100:5.1f}% of HBM peak)")
+
+
+def bench_attn(tag, B, H, Tq, Tk, D, causal, fk):
+    q, k, v = rnd(B, H, Tq, D), rnd(B, H, Tk, D), rnd(B, H, Tk, D)
+    out = torch.empty(B, Tq, H * D, dtype=torch.bfloat16, device=DEV)
+    try:
+        t = timeit(lambda: _lib.attention(q, k, v, 1 / math.sqrt(D), causal=causal, out=out, force_kernel=fk), reps=10)
+    except Exception as e:
+        print(f"attn  {tag}: {e}")
+        return
+    fl = 4.0 * B * H * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0)
+    print(f"attn  {tag:28s} B={B} H={H} Tq={Tq} Tk={Tk} D={D} kernel={fk}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
+
+
+def main():
+    which = sys.argv[1:] or ["gemm", "gemv", "attn"]
+    if "gemm" in which:
+        B = 64
+        Mv = B * 257
+        print("== GEMM (MFMA 128x128x64 tile kernel)")
+        bench_gemm("vit qkv  (B=64)", Mv, 3072, 1024)
+        bench_gemm("vit out  (B=64)", Mv, 1024, 1024)
+        bench_gemm("vit fc1  (B=64)", Mv, 4096, 1024, epi=1)
+        bench_gemm("vit fc2  (B=64)", Mv, 1024, 4096)
+        bench_gemm("vit fc1  (B=1)", 257, 4096, 1024, epi=1)
+        Ml = B * 128
+        bench_gemm("llama qkv (B=64,T=128)", Ml, 12288, 4096)
+        bench_gemm("llama o", Ml, 4096, 4096)
+        bench_gemm("llama gate-up swiglu", Ml, 22016, 4096, epi=3)
+        bench_gemm("llama down", Ml, 4096, 11008)
+        bench_gemm("llama qkv (B=1,T=128)", 128, 12288, 4096)
+        bench_gemm("llama gate-up (B=1,T=128)", 128, 22016, 4096, epi=3)
+        bench_gemm("llama down (B=1,T=128)", 128, 4096, 11008)
+        bench_gemm("square 4096", 4096, 4096, 4096)
+        bench_gemm("square 8192", 8192, 8192, 8192)
+        bench_gemm("decode M=64 qkv (tile kernel)", 64, 12288, 4096)
+        bench_gemm("decode M=64 gate-up", 64, 22016, 4096, epi=3)
+    if "gemv" in which:
+        print("== GEMV (decode, weight streaming)")
+        for M in (1, 4, 8):
+            bench_gemv("llama qkv", M, 12288, 4096, fused_norm=True)
+            bench_gemv("llama o", M, 4096, 4096)
+            bench_gemv("llama gate-up swiglu", M, 22016, 4096, epi=3, fused_norm=True)
+            bench_gemv("llama down", M, 4096, 11008)
+            bench_gemv("lm_head", M, 49958, 4096, fused_norm=True)
+    if "attn" in which:
+        print("== attention")
+        for fk in (1, 2):
+            bench_attn("vit (B=64)", 64, 16, 257, 257, 64, False, fk)
+            bench_attn("resampler (B=64)", 64, 16, 64, 321, 64, False, fk)
+            bench_attn("llama prefill (B=64,T=128)", 64, 32, 128, 128, 128, True, fk)
+            bench_attn("llama prefill (B=1,T=128)", 1, 32, 128, 128, 128, True, fk)
+            bench_attn("llama prefill (B=4,T=1024)", 4, 32, 1024, 1024, 128, True, fk)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+// attention_decode.hip -- one decode step of LLaMA attention for every (sequence, head), fused:
+//   RoPE(q), RoPE(k_new)  ->  append k_new / v_new to the KV cache  ->  softmax(q K^T / sqrt(d)) V over the cache.
+// Replaces three launches (rope + append, attention) and the q/k round trip through HBM.  HBM-bound: the only
+// large reads are the K and V rows of the cache (ctx * d * 2 elements per head), each read exactly once.
+//
+// Workgroup = one (b, h), 256 threads.  Scores: one key per thread (16-byte row loads), probabilities in LDS;
+// P V: each wave owns every 4th key, lanes own 2 adjacent dims, partial outputs reduced through LDS.
+// Position / context length come from device memory (pos0 + *pos_dev) so the launch is hipGraph-replayable.
+#include "vcla_common.h"
+
+template <typename T, int D> struct RowDot;
+template <int D> struct RowDot<float, D> {
+    __device__ static __forceinline__ float dot(const float* qs, const float* k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(k + c);
+            acc += qs[c] * kv.x + qs[c + 1] * kv.y + qs[c + 2] * kv.z + qs[c + 3] * kv.w;
+        }
+        return acc;
+    }
+};
+template <int D> struct RowDot<bf16_t, D> {
+    __device__ static __forceinline__ float dot(const float* qs, const bf16_t* k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 8) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(k + c);
+            float f[8];
+            bf8_to_f32(kv, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += qs[c + e] * f[e];
+        }
+        return acc;
+    }
+};
+
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
+    const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y;
+}
+template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& a, float& b) {
+    const uint32_t t = *reinterpret_cast<const uint32_t*>(p); a = __uint_as_float(t << 16); b = __uint_as_float(t & 0xffff0000u);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                          const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                          T* __restrict__ out, int H, int ctx_max, int pos0,
+                                                          const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
+                                                          int64_t key_mask_ld, float scale, int sc_cap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qs = smem;              // [D]   roped query
+    float* knew = smem + D;        // [D]   roped new key
+    float* vnew = smem + 2 * D;    // [D]   new value
+    float* red = smem + 3 * D;     // [8]
+    float* part = smem + 3 * D + 8;  // [4][D] partial outputs
+    float* sc = part + 4 * D;      // [sc_cap] scores / probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int pos = pos0 + (pos_dev ? *pos_dev : 0);   // position of the new token = number of cached keys
+    constexpr int HALF = D / 2;
+    const int HD = H * D;
+    const T* row = qkv + (int64_t)b * 3 * HD;
+    T* kbase = kc + ((int64_t)b * H + h) * ctx_max * D;
+    T* vbase = vc + ((int64_t)b * H + h) * ctx_max * D;
+
+    // ---- RoPE on q and k_new (rotate-half form), stage q/k/v in LDS, append k/v to the cache
+    if (tid < HALF) {
+        const float c = Act<T>::rnd(cos_tab[(int64_t)pos * HALF + tid]), s = Act<T>::rnd(sin_tab[(int64_t)pos * HALF + tid]);
+        const float q0 = Act<T>::ld(row + h * D + tid), q1 = Act<T>::ld(row + h * D + tid + HALF);
+        qs[tid] = Act<T>::rnd(q0 * c - q1 * s);
+        qs[tid + HALF] = Act<T>::rnd(q1 * c + q0 * s);
+        const float k0 = Act<T>::ld(row + HD + h * D + tid), k1 = Act<T>::ld(row + HD + h * D + tid + HALF);
+        const float r0 = Act<T>::rnd(k0 * c - k1 * s), r1 = Act<T>::rnd(k1 * c + k0 * s);
+        knew[tid] = r0; knew[tid + HALF] = r1;
+        Act<T>::st(kbase + (int64_t)pos * D + tid, r0);
+        Act<T>::st(kbase + (int64_t)pos * D + tid + HALF, r1);
+    } else if (tid >= 128 && tid < 128 + D) {
+        const int i = tid - 128;
+        const float v = Act<T>::ld(row + 2 * HD + h * D + i);
+        vnew[i] = v;
+        Act<T>::st(vbase + (int64_t)pos * D + i, v);
+    }
+    __syncthreads();
+
+    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS)
+    const int Tk = pos + 1;
+    const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
+    float mx = -INFINITY;
+    for (int j = tid; j < Tk; j += 256) {
+        float sv;
+        if (km && km[j] == 0) sv = -INFINITY;
+        else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
+        else {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < D; ++c) acc += qs[c] * knew[c];
+            sv = scale * acc;
+        }
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    if (mx > -INFINITY)
+        for (int j = tid; j < Tk; j += 256) {
+            const float e = __expf(sc[j] - mx);
+            sc[j] = e;
+            l += e;
+        }
+    l = wave_sum(l);
+    __syncthreads();           // everyone has read red[] (max) before it is reused
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    // probabilities rounded to the activation dtype before P V (HF: softmax(...).to(query.dtype))
+    for (int j = tid; j < Tk; j += 256) sc[j] = (mx > -INFINITY) ? Act<T>::rnd(sc[j] * inv) : 0.f;
+    __syncthreads();
+
+    // ---- P V: key group = tid / HALF (0 .. 256/HALF - 1), dims 2*dl, 2*dl+1
+    constexpr int GROUPS = 256 / HALF;
+    const int grp = tid / HALF, dl = tid % HALF;
+    float o0 = 0.f, o1 = 0.f;
+    int j = grp;
+    for (; j + 3 * GROUPS < pos; j += 4 * GROUPS) {
+        float x0, y0, x1, y1, x2, y2, x3, y3;
+        ld2<T>(vbase + (int64_t)(j) * D + 2 * dl, x0, y0);
+        ld2<T>(vbase + (int64_t)(j + GROUPS) * D + 2 * dl, x1, y1);
+        ld2<T>(vbase + (int64_t)(j + 2 * GROUPS) * D + 2 * dl, x2, y2);
+        ld2<T>(vbase + (int64_t)(j + 3 * GROUPS) * D + 2 * dl, x3, y3);
+        const float p0 = sc[j], p1 = sc[j + GROUPS], p2 = sc[j + 2 * GROUPS], p3 = sc[j + 3 * GROUPS];
+        o0 += p0 * x0 + p1 * x1 + p2 * x2 + p3 * x3;
+        o1 += p0 * y0 + p1 * y1 + p2 * y2 + p3 * y3;
+    }
+    for (; j < pos; j += GROUPS) {
+        float x0, y0;
+        ld2<T>(vbase + (int64_t)j * D + 2 * dl, x0, y0);
+        o0 += sc[j] * x0;
+        o1 += sc[j] * y0;
+    }
+    if (grp == 0) {  // the new token's value comes from LDS
+        o0 += sc[pos] * vnew[2 * dl];
+        o1 += sc[pos] * vnew[2 * dl + 1];
+    }
+    // reduce the GROUPS partial outputs through LDS
+    float* pp = part;            // reuse: [GROUPS][D] <= [4][D] when HALF >= 64; for smaller D reduce in two hops
+    if (GROUPS <= 4) {
+        pp[grp * D + 2 * dl] = o0;
+        pp[grp * D + 2 * dl + 1] = o1;
+        __syncthreads();
+        if (tid < D) {
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < GROUPS; ++g2) v += pp[g2 * D + tid];
+            Act<T>::st(out + (int64_t)b * HD + h * D + tid, v);
+        }
+    } else {
+        // D < 128: several key groups share a wave -> fold groups inside the wave first (xor HALF, 2*HALF, ..)
+#pragma unroll
+        for (int off = HALF; off < 64; off <<= 1) {
+            o0 += __shfl_xor(o0, off, 64);
+            o1 += __shfl_xor(o1, off, 64);
+        }
+        if ((lane / HALF) == 0) {
+            pp[wave * D + 2 * dl] = o0;
+            pp[wave * D + 2 * dl + 1] = o1;
+        }
+        __syncthreads();
+        if (tid < D) Act<T>::st(out + (int64_t)b * HD + h * D + tid, pp[tid] + pp[D + tid] + pp[2 * D + tid] + pp[3 * D + tid]);
+    }
+}
+
+template <typename T, int D>
+static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_tab, const float* sin_tab, void* out, int B,
+                         int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
+                         float scale, hipStream_t s) {
+    const int sc_cap = (ctx_max + 63) & ~63;
+    const size_t lds = (size_t)(3 * D + 8 + 4 * D + sc_cap) * sizeof(float);
+    VCLA_REQUIRE(lds <= 64 * 1024, VCLA_ERR_BAD_SHAPE, "attn_decode: ctx_max=%d needs %zu B of LDS (max 64 KiB)", ctx_max, lds);
+    dim3 grid(H, B);
+    attn_decode_kernel<T, D><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
+                                                    pos_dev, key_mask, key_mask_ld, scale, sc_cap);
+    VCLA_CHECK_LAUNCH("attn_decode_kernel");
+    return VCLA_OK;
+}
+
+extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
+                                      const float* sin_tab, void* out, int B, int H, int d, int ctx_max, int pos0,
+                                      const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
+                                      int dtype, void* stream) {
+    VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode: bad dtype %d", dtype);
+    VCLA_REQUIRE(d == 32 || d == 64 || d == 128, VCLA_ERR_BAD_SHAPE, "attn_decode: head dim %d not in {32,64,128}", d);
+    VCLA_REQUIRE(B >= 0 && H > 0 && ctx_max > 0 && pos0 >= 0 && (pos_dev || pos0 < ctx_max), VCLA_ERR_BAD_SHAPE,
+                 "attn_decode: B=%d H=%d ctx_max=%d pos0=%d", B, H, ctx_max, pos0);
+    VCLA_REQUIRE(qkv && k_cache && v_cache && cos_tab && sin_tab && out, VCLA_ERR_BAD_ARG, "attn_decode: null pointer");
+    VCLA_REQUIRE(vcla_aligned(k_cache, 16) && vcla_aligned(v_cache, 16) && vcla_aligned(qkv, 16), VCLA_ERR_BAD_ARG,
+                 "attn_decode: buffers must be 16-byte aligned");
+    if (B == 0) return VCLA_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, s)
+    if (dtype == VCLA_F32) {
+        if (d == 32) DEC_CASE(float, 32);
+        if (d == 64) DEC_CASE(float, 64);
+        DEC_CASE(float, 128);
+    } else {
+        if (d == 32) DEC_CASE(bf16_t, 32);
+        if (d == 64) DEC_CASE(bf16_t, 64);
+        DEC_CASE(bf16_t, 128);
+    }
+#undef DEC_CASE
+}

@@ -1,5 +1,240 @@
-// attention_mfma.hip -- MFMA flash attention (bf16).  Placeholder until the tuned kernel lands: reports
-// "unsupported" so vcla_attention() uses the generic kernel.
+// attention_mfma.hip -- flash attention on v_mfma_f32_16x16x32_bf16 for the bf16 product path
+// (ViT bidirectional N=257 d=64, resampler cross attention 64 x 321 d=64, LLaMA causal prefill d=128).
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows (two 16-row MFMA
+// tiles) and walks the keys in tiles of 64 staged through LDS once per workgroup.
+//
+// Both products are issued "swapped" so that the softmax row lives in ONE lane column:
+//   S^T = K . Q^T   (A port = K rows from LDS, B port = Q rows from registers)
+//       -> lane (q = lane & 15, g = lane >> 4) holds S[q][key = t*16 + g*4 + r], r = 0..3, t = 0..3
+//   O^T = V^T . P^T (A port = V^T rows from LDS, B port = P^T straight from the S^T accumulators)
+//       -> lane holds O[q][d = dt*16 + g*4 + r]: 4 consecutive d of one query row (8-byte stores), and the
+//          online-softmax rescale is a per-lane scalar.
+// The MFMA k-slots of the PV product are whatever keys the lane already holds: k-slot (g, j) of key-step s is key
+// (2s + j/4)*16 + g*4 + j%4.  V^T is written to LDS with that key permutation, so P never moves between lanes.
+// Row max / row sum need only 2 cross-lane steps (xor 16, xor 32).
+//
+// LDS: K tile [64][D] bf16 and V^T tile [D][64] bf16, 16-byte chunks XOR-swizzled so every ds_read_b128
+// fragment read is bank-conflict-free.  Next tile is prefetched into registers under the MFMAs.
 #include "vcla_common.h"
-bool vcla_attention_mfma_supported(const vcla_attn_args*) { return false; }
-int vcla_attention_mfma(const vcla_attn_args*, void*) { return vcla_fail(VCLA_ERR_BAD_ARG, "attention: MFMA kernel not built"); }
+
+#define FA_KV 64
+#define FA_QB 128
+
+template <int D> __device__ __forceinline__ int fa_k_off(int key, int ch) {
+    if (D == 128) return key * 256 + ((ch ^ (key & 15)) << 4);
+    return key * 128 + ((ch ^ ((key >> 1) & 7)) << 4);
+}
+// byte offset of element (row d, key position p) in the V^T tile ([D][64] bf16, 128-byte rows)
+__device__ __forceinline__ int fa_vt_off(int d, int p) { return d * 128 + ((((p >> 3) ^ ((d >> 1) & 7))) << 4) + ((p & 7) << 1); }
+// position of key (0..63) inside the permuted V^T row
+__device__ __forceinline__ int fa_key_pos(int key) {
+    const int t = key >> 4, g = (key >> 2) & 3, r = key & 3;
+    return ((t >> 1) << 5) + (g << 3) + ((t & 1) << 2) + r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
+    constexpr int KST = D / 32;         // MFMA k-steps over the head dim (Q K^T)
+    constexpr int DT = D / 16;          // 16-wide output d tiles (P V)
+    constexpr int CH = D / 8;           // 16-byte chunks per K/V row
+    constexpr int NLD = (FA_KV * CH) / 256;  // staging loads per thread per operand
+    __shared__ __attribute__((aligned(16))) unsigned char ks[FA_KV * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char vts[D * FA_KV * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * FA_QB;           // first query row of this workgroup
+    const int qw = q0 + wave * 32;               // first query row of this wave
+    const int Tq = a.Tq, Tk = a.Tk;
+    const int coff = Tk - Tq;                    // causal: query i sees keys <= i + coff
+    const bf16_t* qb = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* kb = (const bf16_t*)a.k + b * a.k_bs + h * a.k_hs;
+    const bf16_t* vb = (const bf16_t*)a.v + b * a.v_bs + h * a.v_hs;
+    bf16_t* ob = (bf16_t*)a.o + b * a.o_bs + h * a.o_hs;
+    const int32_t* km = a.key_mask ? a.key_mask + b * a.key_mask_ld : nullptr;
+    const int ql = lane & 15, g = lane >> 4;
+    const bool wave_active = qw < Tq;            // waves past the end only help staging
+
+    // ---- Q fragments (B port): lane (q = ql, g) holds Q[q][ks*32 + g*8 .. +8]
+    bf16x8_t qf[2][KST];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qr = qw + qt * 16 + ql;
+        if (qr >= Tq) qr = Tq - 1;
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            qf[qt][s] = *reinterpret_cast<const bf16x8_t*>(qb + (int64_t)qr * a.q_rs + s * 32 + g * 8);
+    }
+
+    f32x4_t o[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float sl2 = a.scale * 1.44269504088896340736f;  // scores are kept in the log2 domain
+
+    // keys this workgroup needs (causal: up to its last query row)
+    int kv_end = Tk;
+    if (a.causal) {
+        const int last_q = (q0 + FA_QB < Tq ? q0 + FA_QB : Tq) - 1;
+        kv_end = last_q + coff + 1 < Tk ? last_q + coff + 1 : Tk;
+    }
+    const int ntiles = (kv_end + FA_KV - 1) / FA_KV;
+
+    // ---- staging maps
+    uint4 rk[NLD], rv[NLD];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int id = i * 256 + tid, key = id / CH, ch = id % CH;
+            int kg = tile * FA_KV + key;
+            if (kg >= Tk) kg = Tk - 1;  // clamp; masked below
+            rk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)kg * a.k_rs + ch * 8);
+            rv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)kg * a.v_rs + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int id = i * 256 + tid, key = id / CH, ch = id % CH;
+            *reinterpret_cast<uint4*>(ks + fa_k_off<D>(key, ch)) = rk[i];
+            const int p = fa_key_pos(key);
+            const uint32_t w4[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bf16_t val = (bf16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e, p)) = val;
+            }
+        }
+    };
+
+    if (ntiles > 0) load_tile(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < ntiles) load_tile(tile + 1);
+        const int kv0 = tile * FA_KV;
+        // causal: a wave whose rows all precede this tile has nothing to do here
+        const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
+        if (skip) continue;
+
+        // ---- S^T = K Q^T
+        f32x4_t sacc[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s * 4 + g));
+                sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][s], sacc[0][t], 0, 0, 0);
+                sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][s], sacc[1][t], 0, 0, 0);
+            }
+        }
+        // ---- masks + online softmax; lane holds keys kv0 + t*16 + g*4 + r of query rows qw + qt*16 + ql
+        const bool need_mask = (kv0 + FA_KV > Tk) || a.causal || km;
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = qw + qt * 16 + ql;
+            const int klim = a.causal ? (qrow + coff < Tk - 1 ? qrow + coff : Tk - 1) : Tk - 1;  // last visible key
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = sacc[qt][t][r] * sl2;
+                    if (need_mask) {
+                        const int key = kv0 + t * 16 + g * 4 + r;
+                        if (key > klim || (km && key < Tk && km[key] == 0)) sv = -INFINITY;
+                    }
+                    sacc[qt][t][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
+            const float alpha = exp2f(m_run[qt] - m_use);             // exp2(-inf) = 0 on the first tile
+            m_run[qt] = m_new;
+            float ps = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(sacc[qt][t][r] - m_use);
+                    pv[t * 4 + r] = p;
+                    ps += p;
+                }
+            l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            // P^T fragments: key-step s takes S tiles (2s, 2s+1): slots j<4 from tile 2s, j>=4 from tile 2s+1
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 u;
+                u.x = pack_bf2(pv[(2 * s) * 4 + 0], pv[(2 * s) * 4 + 1]);
+                u.y = pack_bf2(pv[(2 * s) * 4 + 2], pv[(2 * s) * 4 + 3]);
+                u.z = pack_bf2(pv[(2 * s + 1) * 4 + 0], pv[(2 * s + 1) * 4 + 1]);
+                u.w = pack_bf2(pv[(2 * s + 1) * 4 + 2], pv[(2 * s + 1) * 4 + 3]);
+                pf[qt][s] = __builtin_bit_cast(bf16x8_t, u);
+            }
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vts + fa_vt_off(dt * 16 + ql, s * 32 + g * 8));
+                o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][s], o[0][dt], 0, 0, 0);
+                o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][s], o[1][dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O[q][d] = o / l ; lane holds d = dt*16 + g*4 + r for query row qw + qt*16 + ql
+    if (!wave_active) return;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qrow = qw + qt * 16 + ql;
+        if (qrow >= Tq) continue;
+        bf16_t* orow = ob + (int64_t)qrow * a.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float v[4] = {o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv};
+            Act<bf16_t>::st4(orow + dt * 16 + g * 4, v);
+        }
+    }
+}
+
+bool vcla_attention_mfma_supported(const vcla_attn_args* a) {
+    if (a->D != 64 && a->D != 128) return false;
+    if (a->tk_dev) return false;           // decode (Tq = 1) stays on the generic kernel
+    if (a->Tq < 16) return false;
+    // 16-byte row alignment for Q/K/V fragment + staging loads, 8-byte for O stores
+    auto ok16 = [](const void* p, int64_t bs, int64_t hs, int64_t rs) {
+        return vcla_aligned(p, 16) && bs % 8 == 0 && hs % 8 == 0 && rs % 8 == 0;
+    };
+    if (!ok16(a->q, a->q_bs, a->q_hs, a->q_rs) || !ok16(a->k, a->k_bs, a->k_hs, a->k_rs) || !ok16(a->v, a->v_bs, a->v_hs, a->v_rs)) return false;
+    if (!vcla_aligned(a->o, 8) || a->o_bs % 4 || a->o_hs % 4 || a->o_rs % 4) return false;
+    return true;
+}
+
+int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
+    dim3 grid((a->Tq + FA_QB - 1) / FA_QB, a->H, a->B);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->D == 128) attn_mfma_kernel<128><<<grid, 256, 0, s>>>(*a);
+    else attn_mfma_kernel<64><<<grid, 256, 0, s>>>(*a);
+    VCLA_CHECK_LAUNCH("attn_mfma_kernel");
+    return VCLA_OK;
+}

@@ -143,16 +143,27 @@ extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, cons
 }
 
 // ------------------------------------------------------------------ argmax (first maximum, like torch.argmax)
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t ld,
-                                                     int64_t* __restrict__ out, int V) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+#define ARGMAX_THREADS 1024
+__global__ __launch_bounds__(ARGMAX_THREADS) void argmax_kernel(const float* __restrict__ logits, int64_t ld,
+                                                                int64_t* __restrict__ out, int V) {
+    __shared__ float sv[ARGMAX_THREADS / 64];
+    __shared__ int si[ARGMAX_THREADS / 64];
     const float* x = logits + (int64_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = threadIdx.x; j < V; j += 256) {
-        const float v = x[j];
-        if (v > best || (v == best && j < bi)) { best = v; bi = j; }   // NaNs never win; index ties -> lowest
+    // 8 independent loads in flight per thread: the row is read once, latency is paid ~V / (8 * 1024) times
+    for (int j0 = threadIdx.x; j0 < V; j0 += ARGMAX_THREADS * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * ARGMAX_THREADS;
+            v[u] = j < V ? x[j] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * ARGMAX_THREADS;
+            if (v[u] > best) { best = v[u]; bi = j; }   // strictly greater: j increases, so ties keep the lowest index
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < ARGMAX_THREADS / 64; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         out[blockIdx.x] = (bi == 0x7fffffff) ? 0 : bi;
     }
@@ -173,7 +184,7 @@ extern "C" int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, in
     VCLA_REQUIRE(B >= 0 && V > 0 && ld >= V, VCLA_ERR_BAD_SHAPE, "argmax: B=%d V=%d ld=%lld", B, V, (long long)ld);
     VCLA_REQUIRE(logits && ids_out, VCLA_ERR_BAD_ARG, "argmax: null pointer");
     if (B == 0) return VCLA_OK;
-    argmax_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, ids_out, V);
+    argmax_kernel<<<B, ARGMAX_THREADS, 0, (hipStream_t)stream>>>(logits, ld, ids_out, V);
     VCLA_CHECK_LAUNCH("argmax_kernel");
     return VCLA_OK;
 }

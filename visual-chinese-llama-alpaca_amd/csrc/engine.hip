@@ -322,12 +322,13 @@ extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
 // ------------------------------------------------------------------ small wrappers
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
-                int grp_rows = 0, int grp_stride = 0, int row_off = 0) {
+                int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f) {
     vcla_gemm_args a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32;
     a.c_group_rows = grp_rows; a.c_group_stride = grp_stride; a.c_row_offset = row_off;
     a.force_kernel = 0;
+    a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
@@ -431,22 +432,38 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     const size_t per = (size_t)B * H * ctx_max * d * e;  // bytes of one K (or V) slab of one layer
     char* kc = (char*)kv_cache + (size_t)(2 * l) * per;
     char* vc = kc + per;
-    RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
-    RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE));
-    RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dt, s));
-    vcla_attn_args a{};
-    a.q = w.qkv; a.k = kc; a.v = vc; a.o = w.ao;
-    a.q_bs = (int64_t)T * 3 * D; a.q_hs = d; a.q_rs = 3 * D;
-    a.k_bs = a.v_bs = (int64_t)H * ctx_max * d; a.k_hs = a.v_hs = (int64_t)ctx_max * d; a.k_rs = a.v_rs = d;
-    a.o_bs = (int64_t)T * D; a.o_hs = d; a.o_rs = D;
-    a.B = B; a.H = H; a.Tq = T; a.D = d; a.scale = 1.0f / sqrtf((float)d); a.causal = 1;
-    a.key_mask = key_mask; a.key_mask_ld = ctx_max;
-    if (pos_dev) { a.Tk = ctx_max; a.tk_dev = pos_dev; a.tk_dev_add = pos0 + T; }
-    else a.Tk = pos0 + T;
-    RUN(vcla_attention(&a, dt, s));
+    // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
+    const bool fused = M <= 8;
+    if (fused) {
+        RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps));
+    } else {
+        RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE));
+    }
+    const float scale = 1.0f / sqrtf((float)d);
+    if (T == 1) {
+        // decode: RoPE + KV append + attention over the cache in one launch
+        RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask,
+                                   ctx_max, scale, dt, s));
+    } else {
+        RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dt, s));
+        vcla_attn_args a{};
+        a.q = w.qkv; a.k = kc; a.v = vc; a.o = w.ao;
+        a.q_bs = (int64_t)T * 3 * D; a.q_hs = d; a.q_rs = 3 * D;
+        a.k_bs = a.v_bs = (int64_t)H * ctx_max * d; a.k_hs = a.v_hs = (int64_t)ctx_max * d; a.k_rs = a.v_rs = d;
+        a.o_bs = (int64_t)T * D; a.o_hs = d; a.o_rs = D;
+        a.B = B; a.H = H; a.Tq = T; a.D = d; a.scale = scale; a.causal = 1;
+        a.key_mask = key_mask; a.key_mask_ld = ctx_max;
+        a.Tk = pos0 + T;
+        RUN(vcla_attention(&a, dt, s));
+    }
     RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE));
-    RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
-    RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+    if (fused) {
+        RUN(gemm(ctx, s, w.x, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, L.ln2g, c.t_eps));
+    } else {
+        RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+    }
     RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE));
     return VCLA_OK;
 }
@@ -494,9 +511,13 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));
     for (int l = 0; l < c.t_layers; ++l)
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask));
-    RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
     float* lg = logits ? logits : w.logits;
-    RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    if (B <= 8) {
+        RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps));
+    } else {
+        RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    }
     if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
     if (advance_pos && pos_dev) {
         advance_pos_kernel<<<1, 1, 0, s>>>(pos_dev);

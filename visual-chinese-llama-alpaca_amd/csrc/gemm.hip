@@ -219,49 +219,73 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
-template <typename T, typename OutT, int MB, int EPI>
+// R = weight rows per wave (SWIGLU: R/2 gate rows + their R/2 up rows).  Optional fused RMSNorm prologue
+// (norm_gamma != NULL): y = W . (gamma * x * rstd(x)) computed as rstd * sum_k w_k (gamma_k x_k), with sum x^2
+// accumulated in the same pass -- the decode path needs no separate norm launch and no normalised copy of x.
+template <typename T, typename OutT, int MB, int EPI, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(vcla_gemm_args a) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave index
-    int rows[4];
-    int nvalid;  // rows / outputs this wave really owns
+    int rows[R];
+    int nvalid;  // outputs this wave really owns
     if constexpr (EPI == VCLA_EPI_SWIGLU) {
-        const int j0 = gw * 2;  // output columns j0, j0+1
-        nvalid = (a.N / 2 - j0) < 2 ? (a.N / 2 - j0) : 2;
+        constexpr int P = R / 2;
+        const int j0 = gw * P;  // output columns j0 .. j0+P-1
+        nvalid = (a.N / 2 - j0) < P ? (a.N / 2 - j0) : P;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < P; ++r) {
             const int j = j0 + r;
             rows[r] = (j >> 4) * 32 + (j & 15);  // gate row in the 16-interleaved packing
-            rows[r + 2] = rows[r] + 16;          // matching up row
+            rows[r + P] = rows[r] + 16;          // matching up row
         }
     } else {
-        nvalid = (a.N - gw * 4) < 4 ? (a.N - gw * 4) : 4;
+        nvalid = (a.N - gw * R) < R ? (a.N - gw * R) : R;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rows[r] = gw * 4 + r;
+        for (int r = 0; r < R; ++r) rows[r] = gw * R + r;
     }
     if (nvalid <= 0) return;  // wave-uniform
     const bf16_t* Wg = (const bf16_t*)a.W;
     const T* X = (const T*)a.A;
-    const bf16_t* wp[4];
+    const bf16_t* wp[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wp[r] = Wg + (int64_t)rows[r] * a.K;  // rows beyond N stay inside the 128-row padding
+    for (int r = 0; r < R; ++r) wp[r] = Wg + (int64_t)rows[r] * a.K;  // rows beyond N stay inside the 128-row padding
+                                                                      // (SWIGLU waves are never ragged: N/2 % 16 == 0)
+    const T* xp[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) xp[m] = X + (int64_t)(m < a.M ? m : a.M - 1) * a.lda;
 
-    float acc[4][MB];
+    float acc[R][MB];
+    float ssq[MB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int m = 0; m < MB; ++m) {
+        ssq[m] = 0.f;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+        for (int r = 0; r < R; ++r) acc[r][m] = 0.f;
+    }
+    const bool fused_norm = a.norm_gamma != nullptr;
 
 #pragma unroll 2
     for (int k = lane * 8; k < a.K; k += 512) {
-        uint4 w[4];
+        uint4 w[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = ldg_nt(wp[r] + k);
+        for (int r = 0; r < R; ++r) w[r] = ldg_nt(wp[r] + k);
         float xv[MB][8];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) load8<T>(X + (int64_t)m * a.lda + k, xv[m]);
+        for (int m = 0; m < MB; ++m) load8<T>(xp[m] + k, xv[m]);
+        if (fused_norm) {
+            const float4 g0 = *reinterpret_cast<const float4*>(a.norm_gamma + k);
+            const float4 g1 = *reinterpret_cast<const float4*>(a.norm_gamma + k + 4);
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ssq[m] += xv[m][e] * xv[m][e];
+                    xv[m][e] *= gm[e];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             float wf[8];
             bf8_to_f32(w[r], wf);
 #pragma unroll
@@ -271,22 +295,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(vcla_gemm_args a) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int m = 0; m < MB; ++m) {
+        float sc = 1.f;
+        if (fused_norm) sc = rsqrtf(wave_sum(ssq[m]) / (float)a.K + a.norm_eps);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
+        for (int r = 0; r < R; ++r) acc[r][m] = wave_sum(acc[r][m]) * sc;
+    }
 
-    // lane (m * 4 + r) writes output (m, r)
+    // lane (m * R + r) writes output (m, r)
     OutT* Cg = (OutT*)a.C;
     if constexpr (EPI == VCLA_EPI_SWIGLU) {
+        constexpr int P = R / 2;
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (lane == m * 4 + r && r < nvalid) {
-                    float gt = acc[r][m], up = acc[r + 2][m];
-                    if (a.bias) { gt += a.bias[rows[r]]; up += a.bias[rows[r + 2]]; }
+            for (int r = 0; r < P; ++r) {
+                if (lane == m * R + r && r < nvalid && m < a.M) {
+                    float gt = acc[r][m], up = acc[r + P][m];
+                    if (a.bias) { gt += a.bias[rows[r]]; up += a.bias[rows[r + P]]; }
                     float v = act_silu(gt) * up;
-                    const int n = gw * 2 + r;
+                    const int n = gw * P + r;
                     if (a.residual) v += Act<T>::ld((const T*)a.residual + (int64_t)m * a.ldr + n);
                     Act<OutT>::st(Cg + remap_row(a, m) * a.ldc + n, v);
                 }
@@ -295,8 +323,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(vcla_gemm_args a) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (lane == m * 4 + r && r < nvalid) {
+            for (int r = 0; r < R; ++r) {
+                if (lane == m * R + r && r < nvalid && m < a.M) {
                     float v = acc[r][m];
                     const int n = rows[r];
                     if (a.bias) v += a.bias[n];
@@ -390,19 +418,31 @@ static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
     return VCLA_OK;
 }
 
-template <typename T, typename OutT, int EPI>
-static int launch_gemv(const vcla_gemm_args* a, hipStream_t s) {
-    const int n_units = (EPI == VCLA_EPI_SWIGLU) ? (a->N / 2 + 1) / 2 : (a->N + 3) / 4;  // waves needed
-    const int blocks = (n_units + 3) / 4;
-#define GEMV_CASE(MBV) \
-    case MBV: gemv_kernel<T, OutT, MBV, EPI><<<blocks, 256, 0, s>>>(*a); break;
-    switch (a->M) {
-        GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8)
-        default: return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemv: M=%d > 8", a->M);
-    }
-#undef GEMV_CASE
+template <typename T, typename OutT, int EPI, int R>
+static int launch_gemv_r(const vcla_gemm_args* a, hipStream_t s) {
+    constexpr int per_wave = (EPI == VCLA_EPI_SWIGLU) ? R / 2 : R;  // outputs per wave
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
+    const int waves = (n_out + per_wave - 1) / per_wave;
+    const int blocks = (waves + 3) / 4;
+    if (a->M == 1) gemv_kernel<T, OutT, 1, EPI, R><<<blocks, 256, 0, s>>>(*a);
+    else if (a->M == 2) gemv_kernel<T, OutT, 2, EPI, R><<<blocks, 256, 0, s>>>(*a);
+    else if (a->M <= 4) gemv_kernel<T, OutT, 4, EPI, R><<<blocks, 256, 0, s>>>(*a);
+    else if (a->M <= 8) gemv_kernel<T, OutT, 8, EPI, R><<<blocks, 256, 0, s>>>(*a);
+    else return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemv: M=%d > 8", a->M);
     VCLA_CHECK_LAUNCH("gemv_kernel");
     return VCLA_OK;
+}
+
+template <typename T, typename OutT, int EPI>
+static int launch_gemv(const vcla_gemm_args* a, hipStream_t s) {
+    // enough waves to keep >= 8 per CU in flight: 4 rows per wave only when the matrix is tall
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
+    if (EPI == VCLA_EPI_SWIGLU) {
+        if (n_out >= 4096) return launch_gemv_r<T, OutT, EPI, 4>(a, s);
+        return launch_gemv_r<T, OutT, EPI, 2>(a, s);
+    }
+    if (n_out >= 8192) return launch_gemv_r<T, OutT, EPI, 4>(a, s);
+    return launch_gemv_r<T, OutT, EPI, 2>(a, s);
 }
 
 template <int EPI>
@@ -440,6 +480,8 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(!(kernel == 1 && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernel needs bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
     VCLA_REQUIRE(!(kernel == 2 && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
+    VCLA_REQUIRE(!a->norm_gamma || kernel == 2, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
+    VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {
         case VCLA_EPI_NONE: return dispatch_epi<VCLA_EPI_NONE>(a, dtype, kernel, s);

@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("epilogue", C.c_int), ("out_f32", C.c_int),
         ("c_group_rows", C.c_int), ("c_group_stride", C.c_int), ("c_row_offset", C.c_int),
         ("force_kernel", C.c_int),
+        ("norm_gamma", C.c_void_p), ("norm_eps", C.c_float),
     ]
 
 
@@ -80,6 +81,7 @@ SYMBOLS = {
     "vcla_attention": (_i, [C.POINTER(AttnArgs), _i, _vp]),
     "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _vp]),
     "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
     "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "vcla_ctx_destroy": (None, [_vp]),
@@ -170,7 +172,7 @@ def rmsnorm(x, gamma, eps, out=None):
 
 
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
-         group_rows=0, group_stride=0, row_offset=0):
+         group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out]."""
     lib = load()
     M, K = a.shape
@@ -187,6 +189,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args.epilogue, args.out_f32 = epilogue, int(bool(out_f32))
     args.c_group_rows, args.c_group_stride, args.c_row_offset = group_rows, group_stride, row_offset
     args.force_kernel = force_kernel
+    args.norm_gamma, args.norm_eps = ptr(norm_gamma), float(norm_eps)
     check(lib.vcla_gemm(C.byref(args), dtype_code(a.dtype), stream_ptr()))
     return out
 
