@@ -101,12 +101,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
             const int id = i * 256 + tid, key = id / CH, ch = id % CH;
             *reinterpret_cast<uint4*>(ks + fa_k_off<D>(key, ch)) = rk[i];
             const int p = fa_key_pos(key);
-            const uint32_t w4[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bf16_t val = (bf16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e, p)) = val;
-            }
+            auto put2 = [&](uint32_t w, int e) {  // two adjacent d values of one key -> rows d, d+1 of V^T
+                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e, p)) = (bf16_t)(w & 0xffffu);
+                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e + 1, p)) = (bf16_t)(w >> 16);
+            };
+            put2(rv[i].x, 0); put2(rv[i].y, 2); put2(rv[i].z, 4); put2(rv[i].w, 6);
         }
     };
 
@@ -115,7 +114,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
         __syncthreads();  // previous tile fully consumed
         store_tile();
         __syncthreads();
-        if (tile + 1 < ntiles) load_tile(tile + 1);
+        load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
+                                                         // prefetch registers out of scratch
         const int kv0 = tile * FA_KV;
         // causal: a wave whose rows all precede this tile has nothing to do here
         const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
@@ -137,7 +137,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
             }
         }
         // ---- masks + online softmax; lane holds keys kv0 + t*16 + g*4 + r of query rows qw + qt*16 + ql
-        const bool need_mask = (kv0 + FA_KV > Tk) || a.causal || km;
+        // key-padding mask of the 64 keys of this tile as a wave-uniform bit mask (one load per lane + ballot)
+        unsigned long long tmask = ~0ull;
+        if (km) {  // wave-uniform
+            int key = kv0 + lane;
+            key = key < Tk ? key : Tk - 1;
+            tmask = __ballot(km[key] != 0);
+        }
+        const unsigned long long lmask = tmask >> (g * 4);   // bit (t*16 + r) = key t*16 + g*4 + r
         bf16x8_t pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -148,11 +155,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float sv = sacc[qt][t][r] * sl2;
-                    if (need_mask) {
-                        const int key = kv0 + t * 16 + g * 4 + r;
-                        if (key > klim || (km && key < Tk && km[key] == 0)) sv = -INFINITY;
-                    }
+                    const int key = kv0 + t * 16 + g * 4 + r;
+                    const bool ok = (key <= klim) & (((lmask >> (t * 16 + r)) & 1ull) != 0);
+                    const float sv = ok ? sacc[qt][t][r] * sl2 : -INFINITY;
                     sacc[qt][t][r] = sv;
                     mx = fmaxf(mx, sv);
                 }

@@ -46,16 +46,17 @@ __device__ __forceinline__ bool vcla_aligned_dev(const void* p, size_t a) { retu
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch.bfloat16 conversion)
+// fp32 -> bf16, round-to-nearest-even (same rounding as torch.bfloat16 conversion).  The native __bf16 cast lowers to
+// gfx950's v_cvt_pk_bf16_f32: branch-free, one instruction per pair.
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
 }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // activation-dtype I/O: T = float or bf16_t
