@@ -49,26 +49,25 @@ def parse():
 
 
 def gemv_roofline(model, n_rep: int = 20):
-    """Dominant kernel at B=1: gemv_kernel<bf16,bf16,1,EPI_NONE> (the qkv / o / down projections of every layer; 54 % of
-    the weight bytes of a decode step).  Launches one layer's three shapes back to back on the current stream between two
-    HIP events and reports algorithmic bytes (= weight bytes, each read exactly once) / mean launch duration."""
+    """Dominant kernel of the B=1 workload: the gate/up SwiGLU GEMV with fused RMSNorm
+    (gemv_kernel<bf16,bf16,M=1,EPI_SWIGLU,R=4>; ~34 % of the decode time, 43 % of the weight bytes).  One launch streams
+    W_gu [2*11008, 4096] bf16 exactly once: algorithmic bytes = 180.4 MB.  The 32 layers' matrices are launched back to
+    back (5.8 GB footprint, so nothing is served from the 256 MB Infinity Cache) between two HIP events on the current
+    stream; achieved = bytes / mean launch duration (inter-launch gaps included -> a conservative figure)."""
     from visualcla import _lib
     t = model.config.text_config
     D, I = t["hidden_size"], t["intermediate_size"]
     P = model._packed
     dev = model.device
     x = torch.randn(1, D, device=dev).to(torch.bfloat16)
-    xi = torch.randn(1, I, device=dev).to(torch.bfloat16)
     layers = t["num_hidden_layers"]
-    shapes = []
-    for l in range(layers):
-        shapes += [(x, P[f"llama.l{l}.wqkv"], 3 * D), (x, P[f"llama.l{l}.wo"], D), (xi, P[f"llama.l{l}.wd"], D)]
-    outs = {n: torch.empty(1, n, dtype=torch.bfloat16, device=dev) for n in (3 * D, D)}
-    alg_bytes = sum(n * a.shape[1] * 2 for a, _, n in shapes)
+    out = torch.empty(1, I, dtype=torch.bfloat16, device=dev)
+    alg_bytes = 2 * I * D * 2
 
     def run():
-        for a, w, n in shapes:
-            _lib.gemm(a, w, n, out=outs[n], force_kernel=2)
+        for l in range(layers):
+            _lib.gemm(x, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, force_kernel=2,
+                      norm_gamma=P[f"llama.l{l}.ln2.g"], norm_eps=1e-6)
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,13 +77,12 @@ def gemv_roofline(model, n_rep: int = 20):
     e1.record()
     torch.cuda.synchronize()
     total_ms = e0.elapsed_time(e1)
-    launches = n_rep * len(shapes)
+    launches = n_rep * layers
     avg_us = total_ms * 1e3 / launches
-    # includes the ~1-2 us inter-kernel gaps of back-to-back launches: a conservative (lower) bandwidth figure
-    achieved = (alg_bytes * n_rep) / (total_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,M=1,EPI_NONE>", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "alg_bytes_per_launch": alg_bytes // len(shapes), "avg_launch_us": round(avg_us, 2), "launches_timed": launches}
+    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,M=1,EPI_SWIGLU,R=4> (gate/up + fused RMSNorm)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2), "launches_timed": launches}
 
 
 def cpu_baseline(model, cfg_o, prompt_len: int, new_tokens: int, sample_tokens: int):

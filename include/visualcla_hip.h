@@ -118,6 +118,10 @@ typedef struct vcla_gemm_args {
 /* C = epilogue(A . W^T + bias) (+ residual) */
 int vcla_gemm(const vcla_gemm_args* args, int dtype, void* stream);
 
+/* Tuning harness (not used by the product path): the M = 1 bf16 GEMV with its streaming knobs exposed.
+   variant = rows_per_wave | k_unroll << 8 | x_in_lds << 16 | nontemporal << 17 | waves_per_block << 20. */
+int vcla_gemv_tune(const vcla_gemm_args* args, int variant, void* stream);
+
 /* pixel_values [B, C, H, W] -> patches [B * (H/P) * (W/P), k_pad]; column order (c, ky, kx), zero padded */
 int vcla_im2col(const void* pixels, void* patches, int B, int C, int H, int W, int P, int k_pad, int dtype,
                 void* stream);

@@ -111,11 +111,11 @@ def _gemm_ref(a, w, bias, epi, residual):
 GEMM_SHAPES = [
     # M, N, K
     (1, 256, 128), (3, 1000, 256), (8, 4096, 512), (16, 128, 64), (130, 200, 192), (257, 384, 128),
-    (514, 1024, 1024), (64, 320, 640),
+    (514, 1024, 1024), (64, 320, 640), (700, 1000, 2048),
 ]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "gemv", "gemv32", "f32"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "gemv", "gemv32", "f32"])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm(lib, kernel, epi, M, N, K):
@@ -131,7 +131,7 @@ def test_gemm(lib, kernel, epi, M, N, K):
     n_out = N // 2 if epi == 3 else N
     res = bf16r(torch.randn(M, n_out, generator=g))
     ref = _gemm_ref(a, w, bias, epi, res)
-    fk = {"mfma": 1, "gemv": 2, "gemv32": 2, "f32": 3}[kernel]
+    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "gemv": 2, "gemv32": 2, "f32": 3}[kernel]
     got = lib.gemm(a.to(DEV, dtype), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, dtype), epilogue=epi,
                    force_kernel=fk)
     # inputs are exactly representable; products are exact in fp32; only accumulation order differs (+ one bf16
@@ -180,6 +180,9 @@ def test_gemm_in_place_residual(lib):
     xd = x.to(DEV, torch.bfloat16)
     lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, residual=xd, out=xd, force_kernel=1)
     _cmp("gemm_inplace_residual", xd, ref, atol=2e-3, rtol=8e-3)
+    xd = x.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, residual=xd, out=xd, force_kernel=4)
+    _cmp("gemm256_inplace_residual", xd, ref, atol=2e-3, rtol=8e-3)
 
 
 def test_gemm_full_size_shapes_vs_torch(lib):
@@ -191,8 +194,9 @@ def test_gemm_full_size_shapes_vs_torch(lib):
         ref = _gemm_ref(a.float(), w.float(), None, epi, None)
         wp = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16, device=DEV)
         wp[:N] = w
-        got = lib.gemm(a, wp, N, epilogue=epi, out_f32=True, force_kernel=1)
-        _cmp(f"gemm_full[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=2e-3)
+        for fk in (1, 4):
+            got = lib.gemm(a, wp, N, epilogue=epi, out_f32=True, force_kernel=fk)
+            _cmp(f"gemm_full[k{fk},{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=2e-3)
 
 
 def test_gemm_error_conventions(lib):
@@ -377,11 +381,12 @@ def test_attn_decode_fused(lib, dtype, B, H, d, pos):
     kc_d, vc_d = kc.to(DEV, dtype), vc.to(DEV, dtype)
     qkv_d = qkv.reshape(B, 3 * H * d).to(DEV, dtype).contiguous()
     out = torch.empty(B, H * d, dtype=dtype, device=DEV)
-    pos_dev = torch.tensor([2], dtype=torch.int32, device=DEV)
+    dev_part = min(2, pos)               # position = pos0 + *pos_dev, split between the host and the device counter
+    pos_dev = torch.tensor([dev_part], dtype=torch.int32, device=DEV)
     cos_d, sin_d, km_d = cos.to(DEV), sin.to(DEV), km.to(DEV)
     L = lib.load()
     lib.check(L.vcla_attn_decode_fused(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(),
-                                       out.data_ptr(), B, H, d, ctx, pos - 2, pos_dev.data_ptr(), km_d.data_ptr(), ctx,
+                                       out.data_ptr(), B, H, d, ctx, pos - dev_part, pos_dev.data_ptr(), km_d.data_ptr(), ctx,
                                        1 / math.sqrt(d), lib.dtype_code(dtype), lib.stream_ptr()))
     torch.cuda.synchronize()
     _cmp(f"attn_decode_fused[{dtype},B{B}H{H}d{d}pos{pos}]", out.view(B, 1, H * d), ref, atol=3e-5 if dtype == torch.float32 else 1.5e-2)

@@ -118,7 +118,7 @@ def test_eos_stops_and_pads(golden_dir):
 def test_left_padding_mask_matches_oracle():
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)
-    px, ids, mask = O.make_inputs(cfg, 2, 34)
+    px, ids, mask = O.make_inputs(cfg, 2, 34, n_prefix=5)
     # left-pad sample 1 by 3 tokens (pad id 0), as a batched chat() would (the tail keeps the </img> marker)
     ids[1] = torch.cat([torch.zeros(3, dtype=ids.dtype), ids[1, :-3]])
     mask[1, :3] = 0

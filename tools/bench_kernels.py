@@ -54,6 +54,59 @@ def bench_gemv(tag, M, N, K, epi=0, fused_norm=False):
     print(f"gemv  {tag:28s} M={M:6d} N={N:6d} K={K:6d} epi={epi}  {t*1e6:9.1f} us  {gbs:8.1f} GB/s  ({gbs/8000*100:5.1f}% of HBM peak)")
 
 
+def bench_gemv_tune():
+    """Every streaming variant on the real decode shapes, rotating over 8 weight buffers (> 256 MB MALL) so that the
+    number is an HBM number, not an Infinity-Cache one."""
+    import ctypes as C
+    lib = _lib.load()
+    shapes = [("qkv", 12288, 4096, 0, True), ("o", 4096, 4096, 0, False), ("gate-up", 22016, 4096, 3, True),
+              ("down", 4096, 11008, 0, False)]
+    NBUF = 8
+    for tag, N, K, epi, fused in shapes:
+        ws = [packw(N, K) for _ in range(NBUF)]
+        x = rnd(1, K)
+        gamma = torch.ones(K, device=DEV) if fused else None
+        out = torch.empty(1, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+        res = []
+        def mk(w):
+            a = _lib.GemmArgs()
+            a.A, a.lda, a.W, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), out.data_ptr(), out.shape[1]
+            a.M, a.N, a.K, a.epilogue = 1, N, K, epi
+            a.norm_gamma, a.norm_eps = _lib.ptr(gamma), 1e-6
+            return a
+        argsl = [mk(w) for w in ws]
+        # production kernel first
+        def prod():
+            for w in ws:
+                _lib.gemm(x, w, N, epilogue=epi, out=out, force_kernel=2, norm_gamma=gamma, norm_eps=1e-6)
+        t = timeit(prod, reps=5) / NBUF
+        print(f"tune  {tag:8s} production gemv_kernel                 {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s")
+        for wpb in (4, 8):
+            for xl, nt in ((0, 1), (1, 1), (1, 0)):
+                if wpb == 8 and (xl, nt) == (1, 0):
+                    continue
+                for R in (1, 2, 4, 8):
+                    if epi == 3 and R < 2:
+                        continue
+                    for U in (1, 2, 4):
+                        var = R | (U << 8) | (xl << 16) | (nt << 17) | (wpb << 20)
+                        def run():
+                            for a in argsl:
+                                rc = lib.vcla_gemv_tune(C.byref(a), var, _lib.stream_ptr())
+                                if rc:
+                                    raise RuntimeError(lib.vcla_last_error().decode())
+                        try:
+                            t = timeit(run, reps=5) / NBUF
+                        except Exception as e:
+                            print(f"tune  {tag} var R={R} U={U} xlds={xl} nt={nt} wpb={wpb}: {e}")
+                            continue
+                        res.append((N * K * 2 / t / 1e9, R, U, xl, nt, wpb, t))
+        res.sort(reverse=True)
+        for gbs, R, U, xl, nt, wpb, t in res[:6] + res[-2:]:
+            print(f"tune  {tag:8s} R={R} U={U} xlds={xl} nt={nt} wpb={wpb}            {t*1e6:8.1f} us  {gbs:8.1f} GB/s")
+        del ws
+
+
 def bench_attn(tag, B, H, Tq, Tk, D, causal, fk):
     q, k, v = rnd(B, H, Tq, D), rnd(B, H, Tk, D), rnd(B, H, Tk, D)
     out = torch.empty(B, Tq, H * D, dtype=torch.bfloat16, device=DEV)
@@ -89,6 +142,18 @@ def main():
         bench_gemm("square 8192", 8192, 8192, 8192)
         bench_gemm("decode M=64 qkv (tile kernel)", 64, 12288, 4096)
         bench_gemm("decode M=64 gate-up", 64, 22016, 4096, epi=3)
+        for fk, nm in ((4, "256x256 glds +sched"), (5, "256x256 glds")):
+            print(f"== GEMM ({nm})")
+            bench_gemm("vit qkv  (B=64)", Mv, 3072, 1024, fk=fk)
+            bench_gemm("vit out  (B=64)", Mv, 1024, 1024, fk=fk)
+            bench_gemm("vit fc1  (B=64)", Mv, 4096, 1024, epi=1, fk=fk)
+            bench_gemm("vit fc2  (B=64)", Mv, 1024, 4096, fk=fk)
+            bench_gemm("llama qkv (B=64,T=128)", Ml, 12288, 4096, fk=fk)
+            bench_gemm("llama o", Ml, 4096, 4096, fk=fk)
+            bench_gemm("llama gate-up swiglu", Ml, 22016, 4096, epi=3, fk=fk)
+            bench_gemm("llama down", Ml, 4096, 11008, fk=fk)
+            bench_gemm("square 4096", 4096, 4096, 4096, fk=fk)
+            bench_gemm("square 8192", 8192, 8192, 8192, fk=fk)
     if "gemv" in which:
         print("== GEMV (decode, weight streaming)")
         for M in (1, 4, 8):
@@ -97,6 +162,9 @@ def main():
             bench_gemv("llama gate-up swiglu", M, 22016, 4096, epi=3, fused_norm=True)
             bench_gemv("llama down", M, 4096, 11008)
             bench_gemv("lm_head", M, 49958, 4096, fused_norm=True)
+    if "tune" in which:
+        print("== GEMV tuning (rotating buffers, HBM-resident)")
+        bench_gemv_tune()
     if "attn" in which:
         print("== attention")
         for fk in (1, 2):

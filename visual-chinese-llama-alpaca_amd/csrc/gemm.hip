@@ -27,6 +27,84 @@ __device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
     return (int64_t)(m / a.c_group_rows) * a.c_group_stride + (m % a.c_group_rows) + a.c_row_offset;
 }
 
+// ---- shared MFMA epilogue.  The wave owns MI x 4 accumulator tiles of 16x16 (operands swapped, see header):
+// acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
+// columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
+template <int EPI, typename OutT, int MI>
+__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][4], int mw, int nw, int lane) {
+    const int mrow = lane & 15, nq = (lane >> 4) * 4;
+    OutT* Cg = (OutT*)a.C;
+    constexpr bool kF32 = sizeof(OutT) == 4;
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
+    const bool vec_c = (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
+    const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 16 + mrow;
+        if (m >= a.M) continue;
+        const int64_t crow = remap_row(a, m);
+#pragma unroll
+        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? 2 : 4); ++j) {
+            float v[4];
+            int n;  // first output column of this lane's 4
+            if constexpr (EPI == VCLA_EPI_SWIGLU) {
+                n = nw / 2 + j * 16 + nq;
+                const int np_ = nw + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
+                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
+                    v[r] = act_silu(gt) * up;
+                }
+            } else {
+                n = nw + j * 16 + nq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r];
+                    if (a.bias && n + r < a.N) x += a.bias[n + r];
+                    v[r] = epi_act<EPI>(x);
+                }
+            }
+            if (n >= n_out) continue;
+            if (a.residual) {
+                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
+                if (vec_r && n + 3 < n_out) {
+                    float rv[4];
+                    Act<bf16_t>::ld4(rp, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < n_out) v[r] += bf2f(rp[r]);
+                }
+            }
+            OutT* cp = Cg + crow * a.ldc + n;
+            if (vec_c && n + 3 < n_out) {
+                Act<OutT>::st4(cp, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out) Act<OutT>::st(cp + r, v[r]);
+            }
+        }
+    }
+}
+
+// XCD-aware tile order shared by both MFMA kernels: block b runs on XCD b % 8, so give each XCD a contiguous run of
+// tiles (bijective for any block count), then sweep N inside groups of GRP m-tiles so A panels stay L2-resident.
+__device__ __forceinline__ void tile_assign(int bid, int tiles_m, int tiles_n, int GRP, int& tm, int& tn) {
+    const int nblk = tiles_m * tiles_n;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_grp = GRP * tiles_n;
+    const int g = bid / per_grp;
+    const int gm0 = g * GRP;
+    const int gsz = (tiles_m - gm0) < GRP ? (tiles_m - gm0) : GRP;
+    tm = gm0 + (bid % per_grp) % gsz;
+    tn = (bid % per_grp) / gsz;
+}
+
 // =================================================================== MFMA kernel
 #define GM_BM 128
 #define GM_BN 128
@@ -39,21 +117,8 @@ template <int EPI, typename OutT>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GM_BM * GM_BK * 2];  // [buf][A|W][16 KiB]
 
-    // ---- tile assignment: XCD-aware (block b runs on XCD b % 8; give each XCD a contiguous run of tiles),
-    // then group 8 m-tiles per n-sweep so that A panels stay L2-resident while W panels stream.
-    const int nblk = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int GRP = 8;
-    const int per_grp = GRP * tiles_n;
-    const int g = bid / per_grp;
-    const int gm0 = g * GRP;
-    const int gsz = (tiles_m - gm0) < GRP ? (tiles_m - gm0) : GRP;
-    const int tm = gm0 + (bid % per_grp) % gsz;
-    const int tn = (bid % per_grp) / gsz;
+    int tm, tn;
+    tile_assign(blockIdx.x, tiles_m, tiles_n, 8, tm, tn);
     const int m0 = tm * GM_BM, n0 = tn * GM_BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,66 +204,102 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
     }
     compute_tile((nk - 1) & 1);
 
-    // ---- epilogue.  acc[i][j][r] = C[m][n] with m = m0 + wm*64 + i*16 + (lane & 15),
-    //                                             n = n0 + wn*64 + j*16 + (lane >> 4)*4 + r
-    const int mrow = lane & 15, nq = (lane >> 4) * 4;
-    OutT* Cg = (OutT*)a.C;
-    constexpr bool kF32 = sizeof(OutT) == 4;
-    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
-    const bool vec_c = (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
-    const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
+    gemm_epilogue<EPI, OutT, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// =================================================================== MFMA kernel, 256x256x64 tile, direct-to-LDS staging
+// 8 waves (2 x 4), 128x64 outputs per wave (8 x 4 MFMA tiles, 128 fp32 accumulators per lane), one workgroup per CU
+// (128 KiB of LDS: 2 buffers x (A 32 KiB + W 32 KiB)).  Tiles are staged with global_load_lds_dwordx4: each wave
+// instruction moves 8 rows x 128 B straight into LDS (no VGPR round trip, no ds_write).  The LDS image of a wave
+// instruction is lane-linear, so the bank-conflict swizzle is applied on the SOURCE side: lane (row, c') fetches global
+// chunk c' ^ f(row), and the fragment reader applies the same XOR.  Tile k+1 streams in under the 64 MFMAs per wave of
+// tile k; one barrier per K tile.
+#define G2_BM 256
+#define G2_BN 256
+#define G2_TILE_BYTES (256 * GM_BK * 2)  // 32 KiB per operand tile
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int EPI, typename OutT, bool SGB>
+__global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB]
+    int tm, tn;
+    tile_assign(blockIdx.x, tiles_m, tiles_n, 4, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- staging: wave w owns pieces w*4 .. w*4+3 of each operand tile; piece = 8 rows x 128 B = one wave instruction
+    const bf16_t* Ag = (const bf16_t*)a.A;
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + mrow;
-        if (m >= a.M) continue;
-        const int64_t crow = remap_row(a, m);
+        const int piece = wave * 4 + i;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (involution shared with lds_off)
+        int am = m0 + row, wr = n0 + row;
+        if (am >= a.M) am = a.M - 1;
+        if (wr >= n_pad) wr = n_pad - 1;
+        asrc[i] = Ag + (int64_t)am * a.lda + chunk * 8;
+        wsrc[i] = Wg + (int64_t)wr * a.K + chunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* ab = lds2 + buf * 2 * G2_TILE_BYTES;
+        unsigned char* wb = ab + G2_TILE_BYTES;
 #pragma unroll
-        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? 2 : 4); ++j) {
-            float v[4];
-            int n;  // first output column of this lane's 4
-            if constexpr (EPI == VCLA_EPI_SWIGLU) {
-                // packed tiles (2j, 2j+1) = (gate, up) of output columns (n0 + wn*64)/2 + j*16 + ...
-                n = (n0 + wn * 64) / 2 + j * 16 + nq;
-                const int np_ = n0 + wn * 64 + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (int64_t)kt * GM_BK), (lds_ptr_t)(ab + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[i] + (int64_t)kt * GM_BK), (lds_ptr_t)(wb + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[8][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
-                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
-                    v[r] = act_silu(gt) * up;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = lane >> 4;
+    const int nk = a.K / GM_BK;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // (compiler adds vmcnt(0)): tile kt has landed for every wave, and buffer cur^1 is no longer read
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const unsigned char* As = lds2 + cur * 2 * G2_TILE_BYTES;
+        const unsigned char* Ws = As + G2_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fch));
+            bf16x8_t af[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * 128 + i * 16 + frow, kk * 4 + fch));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            if (SGB) {
+                // issue order: 6 fragment reads (4 W + 2 A), then 4 MFMAs per further A read, so every ds_read runs
+                // two fragments ahead of the MFMAs that consume it
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-            } else {
-                n = n0 + wn * 64 + j * 16 + nq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r];
-                    if (a.bias && n + r < a.N) x += a.bias[n + r];
-                    v[r] = epi_act<EPI>(x);
-                }
-            }
-            if (n >= n_out) continue;
-            if (a.residual) {
-                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
-                if (vec_r && n + 3 < n_out) {
-                    float rv[4];
-                    Act<bf16_t>::ld4(rp, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < n_out) v[r] += bf2f(rp[r]);
-                }
-            }
-            OutT* cp = Cg + crow * a.ldc + n;
-            if (vec_c && n + 3 < n_out) {
-                Act<OutT>::st4(cp, v);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out) Act<OutT>::st(cp + r, v[r]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
     }
+    gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // =================================================================== GEMV kernel (M <= 8)
@@ -418,6 +519,32 @@ static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
     return VCLA_OK;
 }
 
+template <int EPI, typename OutT, bool SGB>
+static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
+    const int tiles_m = (a->M + G2_BM - 1) / G2_BM, tiles_n = (a->N + G2_BN - 1) / G2_BN;
+    const int n_pad = (a->N + 127) / 128 * 128;
+    const size_t lds = 4 * G2_TILE_BYTES;  // 128 KiB
+    auto kern = gemm_mfma256_kernel<EPI, OutT, SGB>;
+    static bool attr_set = false;          // per instantiation
+    if (!attr_set) {
+        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    kern<<<tiles_m * tiles_n, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);
+    VCLA_CHECK_LAUNCH("gemm_mfma256_kernel");
+    return VCLA_OK;
+}
+
+// Which MFMA tile?  256x256 (1 workgroup / CU) runs ~1.35x the 128x128 kernel (2 / CU) per flop but quantises worse:
+// cost = rounds(ceil) / rounds(exact) / relative speed.
+static bool prefer_256(const vcla_gemm_args* a) {
+    if (a->M < 256 || a->N < 256) return false;
+    const double b256 = (double)((a->M + 255) / 256) * ((a->N + 255) / 256) / 256.0;
+    const double b128 = (double)((a->M + 127) / 128) * ((a->N + 127) / 128) / 512.0;
+    const double c256 = ceil(b256) / b256 / 1.35, c128 = ceil(b128) / b128;
+    return c256 < c128;
+}
+
 template <typename T, typename OutT, int EPI, int R>
 static int launch_gemv_r(const vcla_gemm_args* a, hipStream_t s) {
     constexpr int per_wave = (EPI == VCLA_EPI_SWIGLU) ? R / 2 : R;  // outputs per wave
@@ -449,6 +576,10 @@ template <int EPI>
 static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStream_t s) {
     if (kernel == 1) {
         return a->out_f32 ? launch_mfma<EPI, float>(a, s) : launch_mfma<EPI, bf16_t>(a, s);
+    } else if (kernel == 4) {
+        return a->out_f32 ? launch_mfma256<EPI, float, true>(a, s) : launch_mfma256<EPI, bf16_t, true>(a, s);
+    } else if (kernel == 5) {  // same kernel, compiler-chosen ds_read / MFMA interleave (A/B reference for kernel 4)
+        return a->out_f32 ? launch_mfma256<EPI, float, false>(a, s) : launch_mfma256<EPI, bf16_t, false>(a, s);
     } else if (kernel == 2) {
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
         return a->out_f32 ? launch_gemv<bf16_t, float, EPI>(a, s) : launch_gemv<bf16_t, bf16_t, EPI>(a, s);
@@ -475,9 +606,9 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
                  "gemm: A/W must be 16-byte aligned with lda %% %lld == 0 (lda=%lld)", (long long)aa, (long long)a->lda);
     if (a->M == 0) return VCLA_OK;
     int kernel = a->force_kernel;
-    if (kernel == 0) kernel = (a->M <= 8) ? 2 : (dtype == VCLA_F32 ? 3 : 1);
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 3, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
-    VCLA_REQUIRE(!(kernel == 1 && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernel needs bf16 activations");
+    if (kernel == 0) kernel = (a->M <= 8) ? 2 : (dtype == VCLA_F32 ? 3 : (prefer_256(a) ? 4 : 1));
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 5, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(!((kernel == 1 || kernel >= 4) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
     VCLA_REQUIRE(!(kernel == 2 && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
     VCLA_REQUIRE(!a->norm_gamma || kernel == 2, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");

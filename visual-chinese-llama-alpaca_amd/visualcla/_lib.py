@@ -76,6 +76,7 @@ SYMBOLS = {
     "vcla_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     "vcla_rmsnorm": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     "vcla_gemm": (_i, [C.POINTER(GemmArgs), _i, _vp]),
+    "vcla_gemv_tune": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "vcla_attention": (_i, [C.POINTER(AttnArgs), _i, _vp]),
