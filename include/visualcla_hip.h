@@ -108,7 +108,9 @@ typedef struct vcla_gemm_args {
     /* output row remap: row m is stored at row (m / c_group_rows) * c_group_stride +
        (m % c_group_rows) + c_row_offset of C (c_group_rows == 0: identity)                    */
     int c_group_rows, c_group_stride, c_row_offset;
-    int force_kernel;     /* 0 auto; 1 MFMA tile kernel; 2 row-streaming GEMV kernel; 3 fp32 tile */
+    int force_kernel;     /* 0 auto; 1 MFMA 128x128 tile; 2 GEMV (M <= 8); 3 fp32 tile; 4 MFMA 256x256 direct-to-LDS;
+                             5 = 4 without the hand-placed ds_read/MFMA interleave; 6 generic GEMV (no LDS x staging);
+                             7 skinny MFMA (2 <= M <= 128, W streamed once, intra-workgroup split-K) */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */

@@ -111,16 +111,18 @@ def _gemm_ref(a, w, bias, epi, residual):
 GEMM_SHAPES = [
     # M, N, K
     (1, 256, 128), (3, 1000, 256), (8, 4096, 512), (16, 128, 64), (130, 200, 192), (257, 384, 128),
-    (514, 1024, 1024), (64, 320, 640), (700, 1000, 2048),
+    (514, 1024, 1024), (64, 320, 640), (700, 1000, 2048), (2, 512, 4096), (33, 4096, 1408), (128, 288, 2048), (1, 4096, 11008),
 ]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "gemv", "gemv32", "f32"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "skinny", "gemv", "gemv_generic", "gemv32", "f32"])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm(lib, kernel, epi, M, N, K):
     if kernel.startswith("gemv") and M > 8:
         pytest.skip("gemv kernel is for M <= 8")
+    if kernel == "skinny" and M > 128:
+        pytest.skip("skinny kernel is for M <= 128")
     if epi == 3:
         N = (N + 31) // 32 * 32
     g = torch.Generator().manual_seed(M * 1000 + N + K + epi)
@@ -131,7 +133,7 @@ def test_gemm(lib, kernel, epi, M, N, K):
     n_out = N // 2 if epi == 3 else N
     res = bf16r(torch.randn(M, n_out, generator=g))
     ref = _gemm_ref(a, w, bias, epi, res)
-    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "gemv": 2, "gemv32": 2, "f32": 3}[kernel]
+    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
     got = lib.gemm(a.to(DEV, dtype), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, dtype), epilogue=epi,
                    force_kernel=fk)
     # inputs are exactly representable; products are exact in fp32; only accumulation order differs (+ one bf16
@@ -440,3 +442,17 @@ def test_attention_mfma_softmax_rescale_branch(lib):
     ref = _attn_ref(q, k, v, D ** -0.5, False, None)
     got = lib.attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), v.to(DEV, torch.bfloat16), D ** -0.5, force_kernel=2)
     _cmp("attn_mfma_rescale", got, ref, atol=1.5e-2)
+
+
+def test_gemv1_f32_out_bias_residual(lib):
+    """the tuned M = 1 kernel with every optional operand (lm_head-style fp32 output, bias, residual, fused norm)"""
+    g = torch.Generator().manual_seed(77)
+    N, K = 1000, 2048
+    x, w = bf16r(torch.randn(1, K, generator=g)), bf16r(torch.randn(N, K, generator=g) * 0.03)
+    bias, res, gamma = bf16r(torch.randn(N, generator=g)), bf16r(torch.randn(1, N, generator=g)), bf16r(1 + 0.1 * torch.randn(K, generator=g))
+    ref = _gemm_ref(O.llama_rmsnorm(x, gamma, 1e-6), w, bias, 0, res)
+    for fk in (2, 6):
+        got = lib.gemm(x.to(DEV, torch.bfloat16), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), out_f32=True,
+                       force_kernel=fk, norm_gamma=gamma.to(DEV), norm_eps=1e-6)
+        assert got.dtype == torch.float32
+        _cmp(f"gemv1_full[k{fk}]", got, ref, atol=2e-4, rtol=1e-5)

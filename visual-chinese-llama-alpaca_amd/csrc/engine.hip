@@ -433,7 +433,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     char* kc = (char*)kv_cache + (size_t)(2 * l) * per;
     char* vc = kc + per;
     // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
-    const bool fused = M <= 8;
+    const bool fused = (dt == VCLA_F32) ? (M <= 8) : (M == 1);  // must mirror vcla_gemm's kernel choice
     if (fused) {
         RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps));
     } else {
@@ -512,7 +512,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     for (int l = 0; l < c.t_layers; ++l)
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask));
     float* lg = logits ? logits : w.logits;
-    if (B <= 8) {
+    if ((dt == VCLA_F32) ? (B <= 8) : (B == 1)) {
         RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps));
     } else {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));

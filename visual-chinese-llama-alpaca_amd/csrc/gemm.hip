@@ -30,8 +30,8 @@ __device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
 // ---- shared MFMA epilogue.  The wave owns MI x 4 accumulator tiles of 16x16 (operands swapped, see header):
 // acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
 // columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
-template <int EPI, typename OutT, int MI>
-__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][4], int mw, int nw, int lane) {
+template <int EPI, typename OutT, int MI, int NJ = 4>
+__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane) {
     const int mrow = lane & 15, nq = (lane >> 4) * 4;
     OutT* Cg = (OutT*)a.C;
     constexpr bool kF32 = sizeof(OutT) == 4;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
         if (m >= a.M) continue;
         const int64_t crow = remap_row(a, m);
 #pragma unroll
-        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? 2 : 4); ++j) {
+        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? NJ / 2 : NJ); ++j) {
             float v[4];
             int n;  // first output column of this lane's 4
             if constexpr (EPI == VCLA_EPI_SWIGLU) {
@@ -302,6 +302,122 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
     gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// 16-byte non-temporal weight load: streamed-once data should not displace the L2-resident activations
+__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+// =================================================================== skinny MFMA kernel (2 <= M <= 128): batch decode, short prefill
+// HBM-bound by construction: W is streamed exactly once, straight from global memory into MFMA operand registers (no LDS
+// round trip: a weight element is used by one wave only).  Workgroup = WPB waves, output tile = all M rows x 32 columns;
+// the waves split K between them (intra-workgroup split-K), each wave accumulates MT x 2 MFMA tiles over its K slice, the
+// partial tiles are reduced through LDS in a fixed tree order (deterministic), wave 0 runs the shared epilogue.
+// A (activations, M x K, L2-resident) is read as MFMA fragments directly from global/L2.
+#define SK_BN 32
+template <int EPI, typename OutT, int MT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void gemm_skinny_kernel(vcla_gemm_args a) {
+    __shared__ __attribute__((aligned(16))) float4 part[(WPB / 2) * MT * 2 * 64];  // [wave][tile][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * SK_BN;
+    const int frow = lane & 15, g = lane >> 4;
+    const int Kw = a.K / WPB;          // K slice of this wave (multiple of 32, checked on the host)
+    const int kbeg = wave * Kw;
+    const bf16_t* Ag = (const bf16_t*)a.A;
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const bf16_t* wp[2];
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wp[j] = Wg + (int64_t)(n0 + j * 16 + frow) * a.K + kbeg + g * 8;  // rows < N_pad (128-row padding)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = i * 16 + frow;
+        if (m >= a.M) m = a.M - 1;     // clamp: garbage rows are never stored
+        ap[i] = Ag + (int64_t)m * a.lda + kbeg + g * 8;
+    }
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int UN = 4;              // k-steps of 32 issued together (8 weight loads of 16 B in flight per lane)
+    int k = 0;
+    for (; k + 32 * UN <= Kw; k += 32 * UN) {
+        uint4 wv[UN][2];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wv[u][j] = ldg_nt(wp[j] + k + u * 32);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            bf16x8_t af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k + u * 32);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][j]), af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    for (; k < Kw; k += 32) {
+        uint4 wv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wv[j] = ldg_nt(wp[j] + k);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap[i] + k);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]), af, acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- fixed-order tree reduction over the waves: the upper half stores, the lower half adds
+#pragma unroll
+    for (int half = WPB / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    part[((wave - half) * MT * 2 + i * 2 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 p = part[(wave * MT * 2 + i * 2 + j) * 64 + lane];
+                    acc[i][j][0] += p.x; acc[i][j][1] += p.y; acc[i][j][2] += p.z; acc[i][j][3] += p.w;
+                }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) gemm_epilogue<EPI, OutT, MT, 2>(a, acc, 0, n0, lane);
+}
+
+template <int EPI, typename OutT, int MT>
+static int launch_skinny_mt(const vcla_gemm_args* a, hipStream_t s) {
+    const int blocks = (a->N + SK_BN - 1) / SK_BN;
+    // LDS for the partial tiles: (WPB/2) * MT * 2 KiB; MT = 8 fits 64 KiB only with 8 waves -> always legal
+    if (a->K % (32 * 8) == 0) gemm_skinny_kernel<EPI, OutT, MT, 8><<<blocks, 512, 0, s>>>(*a);
+    else gemm_skinny_kernel<EPI, OutT, MT, 2><<<blocks, 128, 0, s>>>(*a);   // K % 64 == 0 always holds
+    VCLA_CHECK_LAUNCH("gemm_skinny_kernel");
+    return VCLA_OK;
+}
+
+template <int EPI, typename OutT>
+static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
+    if (a->M <= 16) return launch_skinny_mt<EPI, OutT, 1>(a, s);
+    if (a->M <= 32) return launch_skinny_mt<EPI, OutT, 2>(a, s);
+    if (a->M <= 64) return launch_skinny_mt<EPI, OutT, 4>(a, s);
+    if (a->M <= 128) return launch_skinny_mt<EPI, OutT, 8>(a, s);
+    return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemm: skinny kernel needs M <= 128 (got %d)", a->M);
+}
+
 // =================================================================== GEMV kernel (M <= 8)
 // x [MB, K] act dtype; each wave owns 4 weight rows (SWIGLU: 2 gate rows + their 2 up rows), lanes stride K by 8.
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
@@ -314,11 +430,6 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
     bf8_to_f32(t, v);
 }
 
-__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
 
 // R = weight rows per wave (SWIGLU: R/2 gate rows + their R/2 up rows).  Optional fused RMSNorm prologue
 // (norm_gamma != NULL): y = W . (gamma * x * rstd(x)) computed as rstd * sum_k w_k (gamma_k x_k), with sum x^2
@@ -435,6 +546,146 @@ __global__ __launch_bounds__(256) void gemv_kernel(vcla_gemm_args a) {
                 }
             }
     }
+}
+
+// =================================================================== M = 1 bf16 GEMV (the decode hot kernel)
+// Configuration picked with tools/bench_kernels.py `tune` on MI355X (profiles/r01_kernel_microbench_run3.txt):
+// x (pre-multiplied by the RMSNorm gain) is staged ONCE per workgroup in LDS as fp32, so the vector-memory queue carries
+// nothing but weight rows; 8 waves per workgroup, 1 row per wave (2 for SwiGLU pairs / very tall matrices), 4 k-steps
+// (4 x 16 B per lane per row) in flight, non-temporal weight loads.  +10..40 % over the generic gemv_kernel.
+template <int R, int U, int WPB, bool SWIGLU, typename OutT>
+__global__ __launch_bounds__(WPB * 64) void gemv1_kernel(vcla_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [K]
+    __shared__ float red[WPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave;
+    const bf16_t* X = (const bf16_t*)a.A;
+    const bool fused_norm = a.norm_gamma != nullptr;
+    float rstd = 1.f;
+    {
+        float ss = 0.f;
+        for (int k = threadIdx.x * 8; k < a.K; k += WPB * 64 * 8) {
+            float xv[8];
+            bf8_to_f32(*reinterpret_cast<const uint4*>(X + k), xv);
+            if (fused_norm) {
+                const float4 g0 = *reinterpret_cast<const float4*>(a.norm_gamma + k);
+                const float4 g1 = *reinterpret_cast<const float4*>(a.norm_gamma + k + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ss += xv[e] * xv[e]; xv[e] *= gm[e]; }
+            }
+            *reinterpret_cast<float4*>(xs + k) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            *reinterpret_cast<float4*>(xs + k + 4) = make_float4(xv[4], xv[5], xv[6], xv[7]);
+        }
+        if (fused_norm) {
+            ss = wave_sum(ss);
+            if (lane == 0) red[wave] = ss;
+        }
+        __syncthreads();
+        if (fused_norm) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) tot += red[w];
+            rstd = rsqrtf(tot / (float)a.K + a.norm_eps);
+        }
+    }
+    constexpr int P = SWIGLU ? R / 2 : R;  // outputs per wave
+    const int n_out = SWIGLU ? a.N / 2 : a.N;
+    if (gw * P >= n_out) return;
+    int rows[R];
+    if (SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int j = gw * P + r;
+            rows[r] = (j >> 4) * 32 + (j & 15);
+            rows[r + P] = rows[r] + 16;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rows[r] = gw * R + r;  // rows past N stay inside the 128-row padding of W
+    }
+    const bf16_t* Wg = (const bf16_t*)a.W;
+    const bf16_t* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wp[r] = Wg + (int64_t)rows[r] * a.K;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+
+    for (int k0 = lane * 8; k0 < a.K; k0 += 512 * U) {
+        uint4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 512;
+            if (k < a.K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = ldg_nt(wp[r] + k);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 512;
+            if (k < a.K) {
+                const float4 x0 = *reinterpret_cast<const float4*>(xs + k), x1 = *reinterpret_cast<const float4*>(xs + k + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float wf[8];
+                    bf8_to_f32(w[u][r], wf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r] += wf[e] * xv[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]) * rstd;
+    OutT* Cg = (OutT*)a.C + remap_row(a, 0) * a.ldc;
+    if (SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < P; ++r)
+            if (lane == r) {
+                float gt = acc[r], up = acc[r + P];
+                if (a.bias) { gt += a.bias[rows[r]]; up += a.bias[rows[r + P]]; }
+                float v = act_silu(gt) * up;
+                const int n = gw * P + r;
+                if (a.residual) v += bf2f(((const bf16_t*)a.residual)[n]);
+                Act<OutT>::st(Cg + n, v);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (lane == r && rows[r] < a.N) {
+                float v = acc[r];
+                if (a.bias) v += a.bias[rows[r]];
+                if (a.residual) v += bf2f(((const bf16_t*)a.residual)[rows[r]]);
+                Act<OutT>::st(Cg + rows[r], v);
+            }
+    }
+}
+
+template <int R, bool SWIGLU, typename OutT>
+static int launch_gemv1(const vcla_gemm_args* a, hipStream_t s) {
+    constexpr int WPB = 8, U = 4;
+    constexpr int P = SWIGLU ? R / 2 : R;
+    const int n_out = SWIGLU ? a->N / 2 : a->N;
+    const int waves = (n_out + P - 1) / P;
+    const int blocks = (waves + WPB - 1) / WPB;
+    gemv1_kernel<R, U, WPB, SWIGLU, OutT><<<blocks, WPB * 64, (size_t)a->K * 4, s>>>(*a);
+    VCLA_CHECK_LAUNCH("gemv1_kernel");
+    return VCLA_OK;
+}
+
+// bf16, M == 1, no activation other than SwiGLU, K*4 bytes of LDS available
+static bool gemv1_applicable(const vcla_gemm_args* a, int dtype) {
+    return dtype == VCLA_BF16 && a->M == 1 && a->K <= 15360 && (a->epilogue == VCLA_EPI_NONE || a->epilogue == VCLA_EPI_SWIGLU);
+}
+static int launch_gemv1_auto(const vcla_gemm_args* a, hipStream_t s) {
+    if (a->epilogue == VCLA_EPI_SWIGLU)
+        return a->out_f32 ? launch_gemv1<2, true, float>(a, s) : launch_gemv1<2, true, bf16_t>(a, s);
+    if (a->N >= 16384)  // very tall (lm_head): 2 rows per wave halves the per-workgroup x staging
+        return a->out_f32 ? launch_gemv1<2, false, float>(a, s) : launch_gemv1<2, false, bf16_t>(a, s);
+    return a->out_f32 ? launch_gemv1<1, false, float>(a, s) : launch_gemv1<1, false, bf16_t>(a, s);
 }
 
 // =================================================================== fp32-activation tile kernel (parity mode)
@@ -580,7 +831,10 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
         return a->out_f32 ? launch_mfma256<EPI, float, true>(a, s) : launch_mfma256<EPI, bf16_t, true>(a, s);
     } else if (kernel == 5) {  // same kernel, compiler-chosen ds_read / MFMA interleave (A/B reference for kernel 4)
         return a->out_f32 ? launch_mfma256<EPI, float, false>(a, s) : launch_mfma256<EPI, bf16_t, false>(a, s);
-    } else if (kernel == 2) {
+    } else if (kernel == 7) {
+        return a->out_f32 ? launch_skinny<EPI, float>(a, s) : launch_skinny<EPI, bf16_t>(a, s);
+    } else if (kernel == 2 || kernel == 6) {
+        if (kernel == 2 && gemv1_applicable(a, dtype)) return launch_gemv1_auto(a, s);
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
         return a->out_f32 ? launch_gemv<bf16_t, float, EPI>(a, s) : launch_gemv<bf16_t, bf16_t, EPI>(a, s);
     } else {
@@ -606,13 +860,19 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
                  "gemm: A/W must be 16-byte aligned with lda %% %lld == 0 (lda=%lld)", (long long)aa, (long long)a->lda);
     if (a->M == 0) return VCLA_OK;
     int kernel = a->force_kernel;
-    if (kernel == 0) kernel = (a->M <= 8) ? 2 : (dtype == VCLA_F32 ? 3 : (prefer_256(a) ? 4 : 1));
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 5, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
-    VCLA_REQUIRE(!((kernel == 1 || kernel >= 4) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
+    if (kernel == 0) {
+        if (dtype == VCLA_F32) kernel = a->M <= 8 ? 2 : 3;
+        else if (a->M == 1 || (a->norm_gamma && a->M <= 8)) kernel = 2;   // GEMV (fused-norm capable)
+        else if (a->M <= 128) kernel = 7;                                  // skinny MFMA: W streamed once
+        else kernel = prefer_256(a) ? 4 : 1;
+    }
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 7, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
-    VCLA_REQUIRE(!(kernel == 2 && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
-    VCLA_REQUIRE(!a->norm_gamma || kernel == 2, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
+    VCLA_REQUIRE(!((kernel == 2 || kernel == 6) && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
+    VCLA_REQUIRE(!a->norm_gamma || kernel == 2 || kernel == 6, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
     VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
+    VCLA_REQUIRE(!(kernel == 7 && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny kernel needs M <= 128 (got %d)", a->M);
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {
         case VCLA_EPI_NONE: return dispatch_epi<VCLA_EPI_NONE>(a, dtype, kernel, s);
