@@ -35,6 +35,13 @@ template <int D> struct RowDot<bf16_t, D> {
     }
 };
 
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) { bf8_to_f32(*reinterpret_cast<const uint4*>(p), v); }
+
 template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
 template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
     const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y;
@@ -84,22 +91,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
-    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS)
+    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS).
+    // Coalesced: LPK = D/8 adjacent lanes read one 16-byte chunk each of the SAME key row (a full row per lane group), the
+    // partial dot products are folded with LPK-wide xor shuffles; a wave covers 64/LPK keys per load instruction.
     const int Tk = pos + 1;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
+    constexpr int LPK = D / 8, KPW = 64 / LPK;
+    const int kc_ = lane % LPK, ksub = lane / LPK;
+    float qreg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qreg[e] = qs[kc_ * 8 + e];
     float mx = -INFINITY;
-    for (int j = tid; j < Tk; j += 256) {
-        float sv;
-        if (km && km[j] == 0) sv = -INFINITY;
-        else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
-        else {
-            float acc = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < D; ++c) acc += qs[c] * knew[c];
-            sv = scale * acc;
+    for (int j0 = wave * KPW; j0 < Tk; j0 += 4 * KPW) {
+        const int j = j0 + ksub;
+        float part_dot = 0.f;
+        if (j < pos) {
+            float kv[8];
+            load8<T>(kbase + (int64_t)j * D + kc_ * 8, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part_dot += qreg[e] * kv[e];
+        } else if (j == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part_dot += qreg[e] * knew[kc_ * 8 + e];
         }
-        sc[j] = sv;
-        mx = fmaxf(mx, sv);
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
+        if (j < Tk) {
+            float sv = scale * part_dot;
+            if (km && km[j] == 0) sv = -INFINITY;
+            if (kc_ == 0) sc[j] = sv;
+            mx = fmaxf(mx, sv);
+        }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
