@@ -110,11 +110,15 @@ typedef struct vcla_gemm_args {
     int c_group_rows, c_group_stride, c_row_offset;
     int force_kernel;     /* 0 auto; 1 MFMA 128x128 tile; 2 GEMV (M <= 8); 3 fp32 tile; 4 MFMA 256x256 direct-to-LDS;
                              5 = 4 without the hand-placed ds_read/MFMA interleave; 6 generic GEMV (no LDS x staging);
-                             7 skinny MFMA (2 <= M <= 128, W streamed once, intra-workgroup split-K) */
+                             7 skinny MFMA (2 <= M <= 128, W streamed once, intra-workgroup split-K);
+                             8 panel MFMA (M <= 128, activations shared through LDS, split-K over workgroups) */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */
     float norm_eps;
+    /* optional fp32 scratch for the split-K panel kernel (kernel 8): >= S * M * N_pad * 4 bytes lets it use S K-slices */
+    void* splitk_ws;
+    size_t splitk_ws_bytes;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

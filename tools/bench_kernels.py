@@ -155,17 +155,19 @@ def main():
             bench_gemm("square 4096", 4096, 4096, 4096, fk=fk)
             bench_gemm("square 8192", 8192, 8192, 8192, fk=fk)
     if "skinny" in which:
-        print("== skinny MFMA GEMM (W streamed once), rotating 4 weight buffers")
-        for M in (2, 8, 16, 32, 64, 128):
+        print("== skinny (k7) / panel split-K (k8) MFMA GEMM, W streamed once, rotating 4 weight buffers")
+        skws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+        for M in (2, 16, 32, 64, 128):
             for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
                 a = rnd(M, K)
                 ws = [packw(N, K) for _ in range(4)]
                 out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
-                def run():
-                    for w in ws:
-                        _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=7)
-                t = timeit(run, reps=10) / 4
-                print(f"skinny {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+                for fk in (7, 8):
+                    def run():
+                        for w in ws:
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws)
+                    t = timeit(run, reps=10) / 4
+                    print(f"k{fk} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
                 del ws
     if "gemv" in which:
         print("== GEMV (decode, weight streaming)")

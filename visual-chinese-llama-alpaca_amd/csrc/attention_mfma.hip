@@ -84,22 +84,22 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
     const int ntiles = (kv_end + FA_KV - 1) / FA_KV;
 
     // ---- staging maps
-    uint4 rk[NLD], rv[NLD];
+    u32x4_t rk[NLD], rv[NLD];
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int id = i * 256 + tid, key = id / CH, ch = id % CH;
             int kg = tile * FA_KV + key;
             if (kg >= Tk) kg = Tk - 1;  // clamp; masked below
-            rk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)kg * a.k_rs + ch * 8);
-            rv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)kg * a.v_rs + ch * 8);
+            rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)kg * a.k_rs + ch * 8);
+            rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kg * a.v_rs + ch * 8);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int id = i * 256 + tid, key = id / CH, ch = id % CH;
-            *reinterpret_cast<uint4*>(ks + fa_k_off<D>(key, ch)) = rk[i];
+            *reinterpret_cast<u32x4_t*>(ks + fa_k_off<D>(key, ch)) = rk[i];
             const int p = fa_key_pos(key);
             auto put2 = [&](uint32_t w, int e) {  // two adjacent d values of one key -> rows d, d+1 of V^T
                 *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e, p)) = (bf16_t)(w & 0xffffu);

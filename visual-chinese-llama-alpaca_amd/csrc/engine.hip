@@ -257,9 +257,11 @@ struct Bump {
     }
 };
 
+#define SPLITK_WS_BYTES ((size_t)32 << 20)   // fp32 scratch for the split-K panel GEMM (M <= 128)
 struct VisionWs {
     void *patches, *patch_emb, *x, *h, *qkv, *mlp;          // ViT
     void *lat, *q, *kv, *ao, *t, *h2, *ffn;                 // resampler
+    void* splitk;
 };
 static size_t carve_vision(const vcla_ctx* ctx, int B, char* base, VisionWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -280,6 +282,7 @@ static size_t carve_vision(const vcla_ctx* ctx, int B, char* base, VisionWs* w) 
     t.t = b.take(B * Q * c.r_hidden * e);
     t.h2 = b.take(B * Q * c.r_hidden * e);
     t.ffn = b.take(B * Q * c.r_inter * e);
+    t.splitk = b.take(SPLITK_WS_BYTES);
     if (w) *w = t;
     return b.off + 256;
 }
@@ -292,6 +295,7 @@ struct LlamaWs {
     void *x, *h, *qkv, *ao, *act, *hl;
     float* logits;
     int64_t* ids;
+    void* splitk;
 };
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -307,6 +311,7 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.hl = b.take((size_t)B * c.t_hidden * e);
     t.logits = (float*)b.take((size_t)B * c.t_vocab * 4);
     t.ids = (int64_t*)b.take((size_t)B * 8);
+    t.splitk = b.take(SPLITK_WS_BYTES);
     if (w) *w = t;
     return b.off + 256;
 }
@@ -320,6 +325,8 @@ extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
 }
 
 // ------------------------------------------------------------------ small wrappers
+static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry points from their workspace carve
+
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
                 int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f) {
@@ -329,6 +336,7 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.c_group_rows = grp_rows; a.c_group_stride = grp_stride; a.c_row_offset = row_off;
     a.force_kernel = 0;
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
+    a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
@@ -359,6 +367,7 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
     const int g = c.v_image / c.v_patch, np = g * g, N = np + 1, D = c.v_hidden, H = c.v_heads, d = D / H;
     VisionWs w;
     carve_vision(ctx, B, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    g_splitk_ws = w.splitk;
     const int M = B * N;
 
     // patch embedding: im2col -> GEMM (no bias) -> class/position embedding + pre-LN
@@ -484,6 +493,7 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     const int D = c.t_hidden, M = B * T;
     LlamaWs w;
     carve_llama(ctx, B, T, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    g_splitk_ws = w.splitk;
     VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < c.t_layers; ++l) {
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, T, pos0, nullptr, kv_cache, ctx_max, key_mask));
@@ -543,6 +553,7 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
     RUN(check_decode_args(ctx, ids_in, B, pos0, pos_dev, kv_cache, ctx_max, ws, ws_bytes));
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    g_splitk_ws = w.splitk;
     return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
                             logits, ids_out, w);
 }
@@ -556,6 +567,7 @@ extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int 
     hipStream_t s = (hipStream_t)stream;
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    g_splitk_ws = w.splitk;
     // w.ids holds the current token of every sequence; each step consumes it and overwrites it with the argmax.
     VCLA_CHECK_HIP(hipMemcpyAsync(w.ids, ids_in, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
     // step_base: value of *pos_dev at the first step is unknown to the host -> the caller passes pos0 as the absolute

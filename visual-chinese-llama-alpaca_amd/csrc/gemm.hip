@@ -418,6 +418,211 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
     return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemm: skinny kernel needs M <= 128 (got %d)", a->M);
 }
 
+// =================================================================== panel MFMA kernel (M <= 128, batch decode), split-K over workgroups
+// Workgroup = 4 waves = all M rows x 128 columns of one K slice; wave w owns columns 32w..32w+31 (2 MFMA n-tiles) and streams
+// ITS weight rows straight from HBM into MFMA operand registers (a weight element is needed by one wave only), 4 K-tiles
+// ahead.  The activation panel A[M, 64] of each K tile is shared by the 4 waves: coalesced full-line loads (4 tiles ahead,
+// register ring) -> swizzled LDS double buffer -> ds_read_b128 fragments.  Every load has the same 4-tile distance, so the
+// in-order vmcnt queue never forces an early wait.  grid = (N/128, S): S K-slices keep >= ~300 workgroups in flight; S > 1
+// writes fp32 partial tiles to a workspace and gemm_panel_reduce_kernel applies the epilogue (fixed summation order).
+#define PN_BN 128
+#define PN_RING 4
+template <int EPI, typename OutT, int MT>
+__global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
+    constexpr int NA = (MT * 128 + 255) / 256;  // 16-byte A chunks per thread per K tile
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][MT * 16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * PN_BN, ks = blockIdx.y;
+    const int nk = a.K / GM_BK;
+    const int t_beg = (int)((int64_t)ks * nk / splitk), t_end = (int)((int64_t)(ks + 1) * nk / splitk);
+    const int nkc = t_end - t_beg;     // K tiles of this slice (>= 1: host guarantees splitk <= nk)
+    const bf16_t* Ag = (const bf16_t*)a.A + (int64_t)t_beg * GM_BK;
+    const bf16_t* Wg = (const bf16_t*)a.W + (int64_t)t_beg * GM_BK;
+
+    // A staging map: chunk id -> (row, 16-byte chunk); rows past M are clamped (never stored).  Every thread always loads
+    // (ids past the tile wrap around) so the register ring stays branch-free; only the LDS store is predicated.
+    auto a_src = [&](int i) {
+        const int id = i * 256 + tid;
+        const int row = (id >> 3) % (MT * 16), ch = id & 7;
+        const int am = row < a.M ? row : a.M - 1;
+        return Ag + (int64_t)am * a.lda + ch * 8;
+    };
+    auto a_dst = [&](int i) {
+        const int id = i * 256 + tid;
+        return lds_off((id >> 3) % (MT * 16), id & 7);
+    };
+    const bf16_t *asrc0 = a_src(0), *asrc1 = a_src(1), *asrc2 = a_src(2), *asrc3 = a_src(3);
+    const int adst0 = a_dst(0), adst1 = a_dst(1), adst2 = a_dst(2), adst3 = a_dst(3);
+    // W fragment rows of this wave: 2 n-tiles; rows past N stay inside the 128-row padding, past n_pad are clamped
+    const bf16_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int wr = n0 + wave * 32 + j * 16 + frow;
+        if (wr >= n_pad) wr = n_pad - 1;
+        wsrc[j] = Wg + (int64_t)wr * a.K + g * 8;
+    }
+    // 4-slot register ring, one named array per slot: slot indices must be literals for the compiler to keep the ring in
+    // VGPRs (a ring indexed through a lambda parameter is demoted to scratch).
+    struct AReg { u32x4_t c0, c1, c2, c3; };  // up to 4 chunks per thread; unused members are never touched (NA < 4)
+    AReg ra0, ra1, ra2, ra3;
+    u32x4_t rw0[4], rw1[4], rw2[4], rw3[4];  // [kk*2 + j]
+    // tiles past the end of the slice re-load the last tile with ZEROED weight fragments: the MFMAs then add 0 and the
+    // ring needs no control flow (the slice length need not be a multiple of 4)
+#define PN_LOAD(tile_, RA, RW)                                                                      \
+    {                                                                                               \
+        const bool valid_ = (tile_) < nkc;                                                          \
+        const int64_t ko_ = (int64_t)(valid_ ? (tile_) : nkc - 1) * GM_BK;                          \
+        RA.c0 = *reinterpret_cast<const u32x4_t*>(asrc0 + ko_);                                       \
+        if (NA >= 2) RA.c1 = *reinterpret_cast<const u32x4_t*>(asrc1 + ko_);                          \
+        if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+            const u32x4_t w_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc[q & 1] + ko_ + (q >> 1) * 32)); \
+            RW[q] = valid_ ? w_ : u32x4_t{0u, 0u, 0u, 0u};                                          \
+        }                                                                                           \
+    }
+#define PN_STORE(RA, buf_)                                                                          \
+    {                                                                                               \
+        if (MT * 128 >= 256 || tid < MT * 128) *reinterpret_cast<u32x4_t*>(&As[buf_][adst0]) = RA.c0; \
+        if (NA >= 2) *reinterpret_cast<u32x4_t*>(&As[buf_][adst1]) = RA.c1;                           \
+        if (NA >= 4) { *reinterpret_cast<u32x4_t*>(&As[buf_][adst2]) = RA.c2; *reinterpret_cast<u32x4_t*>(&As[buf_][adst3]) = RA.c3; } \
+    }
+#define PN_COMPUTE(RW, cur_)                                                                        \
+    {                                                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
+            const bf16x8_t w0_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 0]);                      \
+            const bf16x8_t w1_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 1]);                      \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                        \
+                const bf16x8_t af_ = *reinterpret_cast<const bf16x8_t*>(&As[cur_][lds_off(i * 16 + frow, kk * 4 + g)]); \
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0_, af_, acc[i][0], 0, 0, 0);  \
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1_, af_, acc[i][1], 0, 0, 0);  \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    PN_LOAD(0, ra0, rw0) PN_LOAD(1, ra1, rw1) PN_LOAD(2, ra2, rw2) PN_LOAD(3, ra3, rw3)
+    PN_STORE(ra0, 0)
+    __syncthreads();
+    const int nk4 = (nkc + PN_RING - 1) / PN_RING * PN_RING;
+    for (int kt = 0; kt < nk4; kt += PN_RING) {
+        // tile kt+t: MFMAs from LDS buffer t&1 and ring slot t; park tile kt+t+1 (loaded 3 steps ago) in the other LDS
+        // buffer; refill slot t with tile kt+t+4; one barrier per tile
+        PN_COMPUTE(rw0, 0) PN_STORE(ra1, 1) PN_LOAD(kt + 4, ra0, rw0) __syncthreads();
+        PN_COMPUTE(rw1, 1) PN_STORE(ra2, 0) PN_LOAD(kt + 5, ra1, rw1) __syncthreads();
+        PN_COMPUTE(rw2, 0) PN_STORE(ra3, 1) PN_LOAD(kt + 6, ra2, rw2) __syncthreads();
+        PN_COMPUTE(rw3, 1) PN_STORE(ra0, 0) PN_LOAD(kt + 7, ra3, rw3) __syncthreads();
+    }
+#undef PN_LOAD
+#undef PN_STORE
+#undef PN_COMPUTE
+    if (splitk == 1) {
+        gemm_epilogue<EPI, OutT, MT, 2>(a, acc, 0, n0 + wave * 32, lane);
+    } else {
+        // fp32 partial tile: partial[ks][m][n], 4 consecutive columns per lane (16-byte stores)
+        float* pp = partial + (int64_t)ks * a.M * n_pad;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = i * 16 + frow;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wave * 32 + j * 16 + g * 4;
+                if (n < n_pad)
+                    *reinterpret_cast<float4*>(pp + (int64_t)m * n_pad + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    }
+}
+
+// sum the S partial tiles in slice order, then bias / activation / SwiGLU / residual / store (4 columns per thread)
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(vcla_gemm_args a, int splitk, int n_pad, const float* __restrict__ partial) {
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
+    const int groups = (n_out + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * groups) return;
+    const int m = (int)(idx / groups), n = (int)(idx % groups) * 4;
+    float v[4];
+    if constexpr (EPI == VCLA_EPI_SWIGLU) {
+        const int np_ = (n >> 4) * 32 + (n & 15);  // packed gate column; up = +16
+        float gt[4] = {0, 0, 0, 0}, up[4] = {0, 0, 0, 0};
+        for (int s = 0; s < splitk; ++s) {
+            const float* pp = partial + ((int64_t)s * a.M + m) * n_pad + np_;
+            const float4 x = *reinterpret_cast<const float4*>(pp), y = *reinterpret_cast<const float4*>(pp + 16);
+            gt[0] += x.x; gt[1] += x.y; gt[2] += x.z; gt[3] += x.w;
+            up[0] += y.x; up[1] += y.y; up[2] += y.z; up[3] += y.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (a.bias) { gt[r] += a.bias[np_ + r]; up[r] += a.bias[np_ + 16 + r]; }
+            v[r] = act_silu(gt[r]) * up[r];
+        }
+    } else {
+        float sacc[4] = {0, 0, 0, 0};
+        for (int s = 0; s < splitk; ++s) {
+            const float4 x = *reinterpret_cast<const float4*>(partial + ((int64_t)s * a.M + m) * n_pad + n);
+            sacc[0] += x.x; sacc[1] += x.y; sacc[2] += x.z; sacc[3] += x.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = sacc[r];
+            if (a.bias && n + r < a.N) x += a.bias[n + r];
+            v[r] = epi_act<EPI>(x);
+        }
+    }
+    const int64_t crow = remap_row(a, m);
+    OutT* cp = (OutT*)a.C + crow * a.ldc + n;
+    const bf16_t* rp = a.residual ? (const bf16_t*)a.residual + (int64_t)m * a.ldr + n : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (n + r < n_out) {
+            float x = v[r];
+            if (rp) x += bf2f(rp[r]);
+            Act<OutT>::st(cp + r, x);
+        }
+}
+
+static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
+    const int tiles_n = (a->N + PN_BN - 1) / PN_BN, nk = a->K / GM_BK;
+    int s = (320 + tiles_n / 2) / tiles_n;
+    if (s < 1) s = 1;
+    if (s > 8) s = 8;
+    if (s > nk) s = nk;
+    while (s > 1 && (size_t)s * a->M * n_pad * 4 > a->splitk_ws_bytes) --s;  // no / small workspace -> fewer slices
+    if (!a->splitk_ws) s = 1;
+    return s;
+}
+
+template <int EPI, typename OutT, int MT>
+static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
+    const int n_pad = (a->N + 127) / 128 * 128;
+    const int splitk = panel_splitk(a, n_pad);
+    dim3 grid((a->N + PN_BN - 1) / PN_BN, splitk);
+    gemm_panel_kernel<EPI, OutT, MT><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    VCLA_CHECK_LAUNCH("gemm_panel_kernel");
+    if (splitk > 1) {
+        const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
+        const int64_t work = (int64_t)a->M * ((n_out + 3) / 4);
+        gemm_panel_reduce_kernel<EPI, OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, splitk, n_pad, (const float*)a->splitk_ws);
+        VCLA_CHECK_LAUNCH("gemm_panel_reduce_kernel");
+    }
+    return VCLA_OK;
+}
+
+template <int EPI, typename OutT>
+static int launch_panel(const vcla_gemm_args* a, hipStream_t s) {
+    if (a->M <= 16) return launch_panel_mt<EPI, OutT, 1>(a, s);
+    if (a->M <= 32) return launch_panel_mt<EPI, OutT, 2>(a, s);
+    if (a->M <= 64) return launch_panel_mt<EPI, OutT, 4>(a, s);
+    if (a->M <= 128) return launch_panel_mt<EPI, OutT, 8>(a, s);
+    return vcla_fail(VCLA_ERR_BAD_SHAPE, "gemm: panel kernel needs M <= 128 (got %d)", a->M);
+}
+
 // =================================================================== GEMV kernel (M <= 8)
 // x [MB, K] act dtype; each wave owns 4 weight rows (SWIGLU: 2 gate rows + their 2 up rows), lanes stride K by 8.
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
@@ -833,6 +1038,8 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
         return a->out_f32 ? launch_mfma256<EPI, float, false>(a, s) : launch_mfma256<EPI, bf16_t, false>(a, s);
     } else if (kernel == 7) {
         return a->out_f32 ? launch_skinny<EPI, float>(a, s) : launch_skinny<EPI, bf16_t>(a, s);
+    } else if (kernel == 8) {
+        return a->out_f32 ? launch_panel<EPI, float>(a, s) : launch_panel<EPI, bf16_t>(a, s);
     } else if (kernel == 2 || kernel == 6) {
         if (kernel == 2 && gemv1_applicable(a, dtype)) return launch_gemv1_auto(a, s);
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
@@ -863,16 +1070,17 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     if (kernel == 0) {
         if (dtype == VCLA_F32) kernel = a->M <= 8 ? 2 : 3;
         else if (a->M == 1 || (a->norm_gamma && a->M <= 8)) kernel = 2;   // GEMV (fused-norm capable)
-        else if (a->M <= 128) kernel = 7;                                  // skinny MFMA: W streamed once
+        else if (a->M <= 128) kernel = a->splitk_ws ? 8 : 7;               // panel (split-K) / skinny MFMA: W streamed once
         else kernel = prefer_256(a) ? 4 : 1;
     }
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 7, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
-    VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 8, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
     VCLA_REQUIRE(!((kernel == 2 || kernel == 6) && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
     VCLA_REQUIRE(!a->norm_gamma || kernel == 2 || kernel == 6, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
     VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
-    VCLA_REQUIRE(!(kernel == 7 && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny kernel needs M <= 128 (got %d)", a->M);
+    VCLA_REQUIRE(!((kernel == 7 || kernel == 8) && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny / panel kernels need M <= 128 (got %d)", a->M);
+    VCLA_REQUIRE(!a->splitk_ws || vcla_aligned(a->splitk_ws, 16), VCLA_ERR_BAD_ARG, "gemm: splitk_ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {
         case VCLA_EPI_NONE: return dispatch_epi<VCLA_EPI_NONE>(a, dtype, kernel, s);

@@ -11,6 +11,9 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// native 16-byte vector: use this (not HIP's uint4 struct) for register staging -- struct copies become memcpy in IR and
+// memcpy-only private arrays are not promoted to registers (they end up in scratch)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // ------------------------------------------------------------------ error handling (host)
 void vcla_set_error(const char* fmt, ...);
