@@ -176,6 +176,25 @@ def main():
         dt = float(tt.item())
     assert out.shape == (gB, args.new_tokens), out.shape
 
+    def timed(fn, reps=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    breakdown = None
+    if rank == 0:
+        # stage split of one step (outside the timed region): vision stack, + splice/prefill/first token, + decode
+        t_vis = timed(lambda: model.embed_images(px))
+        kw1 = dict(kw, max_new_tokens=1)
+        t_pre = timed(lambda: model.generate(**kw1))
+        breakdown = {"vision_ms": round(t_vis, 2), "prefill_first_token_ms": round(t_pre - t_vis, 2),
+                     "decode_ms": round(dt / args.steps * 1e3 - t_pre, 2),
+                     "decode_ms_per_token_step": round((dt / args.steps * 1e3 - t_pre) / max(args.new_tokens - 1, 1), 3)}
+
     if rank == 0:
         tokens = gB * args.new_tokens * args.steps
         images = gB * args.steps
@@ -192,6 +211,7 @@ def main():
                        "global_batch": gB, "seq_len": args.prompt_len, "new_tokens": args.new_tokens,
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"},
         }
+        res["breakdown_ms"] = breakdown
         res["roofline"] = gemv_roofline(model)
         if not args.no_cpu_baseline:
             try:

@@ -1070,7 +1070,12 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     if (kernel == 0) {
         if (dtype == VCLA_F32) kernel = a->M <= 8 ? 2 : 3;
         else if (a->M == 1 || (a->norm_gamma && a->M <= 8)) kernel = 2;   // GEMV (fused-norm capable)
-        else if (a->M <= 128) kernel = a->splitk_ws ? 8 : 7;               // panel (split-K) / skinny MFMA: W streamed once
+        else if (a->M <= 128) {
+            // W streamed once.  Measured on MI355X (profiles/r01_kernel_microbench_run5.txt): the split-K panel kernel wins
+            // for M >= 64, for short-N / long-K shapes (down-proj) and for N <= 4096 once M >= 32; else the skinny kernel
+            const bool panel = a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32)));
+            kernel = panel ? 8 : 7;
+        }
         else kernel = prefer_256(a) ? 4 : 1;
     }
     VCLA_REQUIRE(kernel >= 1 && kernel <= 8, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
