@@ -119,6 +119,9 @@ typedef struct vcla_gemm_args {
     /* optional fp32 scratch for the split-K panel kernel (kernel 8): >= S * M * N_pad * 4 bytes lets it use S K-slices */
     void* splitk_ws;
     size_t splitk_ws_bytes;
+    /* optional fragment-major twin of W, [N_pad/16][K/32][64 lanes][8] bf16 (visualcla/weights.py:to_fragment_major):
+       lets the M <= 128 panel kernel stream each 16-row tile as one contiguous region */
+    const void* W_frag;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

@@ -115,13 +115,13 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "skinny", "panel", "panel_ws", "gemv", "gemv_generic", "gemv32", "f32"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "skinny", "panel", "panel_ws", "panel_frag", "gemv", "gemv_generic", "gemv32", "f32"])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm(lib, kernel, epi, M, N, K):
     if kernel.startswith("gemv") and M > 8:
         pytest.skip("gemv kernel is for M <= 8")
-    if kernel in ("skinny", "panel", "panel_ws") and M > 128:
+    if kernel in ("skinny", "panel", "panel_ws", "panel_frag") and M > 128:
         pytest.skip("skinny / panel kernels are for M <= 128")
     if epi == 3:
         N = (N + 31) // 32 * 32
@@ -133,10 +133,16 @@ def test_gemm(lib, kernel, epi, M, N, K):
     n_out = N // 2 if epi == 3 else N
     res = bf16r(torch.randn(M, n_out, generator=g))
     ref = _gemm_ref(a, w, bias, epi, res)
-    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "panel": 8, "panel_ws": 8, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
-    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV) if kernel == "panel_ws" else None
-    got = lib.gemm(a.to(DEV, dtype), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, dtype), epilogue=epi,
-                   force_kernel=fk, splitk_ws=ws)
+    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "panel": 8, "panel_ws": 8, "panel_frag": 8, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV) if kernel in ("panel_ws", "panel_frag") else None
+    wp = _pack(w)
+    wf = None
+    if kernel == "panel_frag":
+        from visualcla.weights import to_fragment_major, from_fragment_major
+        wf = to_fragment_major(wp)
+        assert torch.equal(from_fragment_major(wf), wp)
+    got = lib.gemm(a.to(DEV, dtype), wp, N, bias=bias.to(DEV), residual=res.to(DEV, dtype), epilogue=epi,
+                   force_kernel=fk, splitk_ws=ws, w_frag=wf)
     # inputs are exactly representable; products are exact in fp32; only accumulation order differs (+ one bf16
     # output rounding in bf16 mode)
     if dtype == torch.float32:

@@ -77,6 +77,17 @@ def test_pack_unpack_roundtrip(mk):
     assert torch.equal(p2["vit.l0.wqkv"], packed["vit.l0.wqkv"])
 
 
+def test_fragment_major_layout():
+    """element (n, k) of W sits at [n // 16][k // 32][((k % 32) // 8) * 16 + n % 16][k % 8]"""
+    from visualcla.weights import to_fragment_major, from_fragment_major
+    w = torch.arange(32 * 64, dtype=torch.float32).view(32, 64).to(torch.bfloat16)
+    f = to_fragment_major(w)
+    assert f.shape == (2, 2, 64, 8)
+    for n, k in ((0, 0), (5, 9), (17, 40), (31, 63), (16, 31)):
+        assert f[n // 16, k // 32, ((k % 32) // 8) * 16 + n % 16, k % 8] == w[n, k]
+    assert torch.equal(from_fragment_major(f), w)
+
+
 def test_rope_tables_match_oracle():
     from visualcla.weights import rope_tables
     cos, sin = rope_tables(64, 128, 10000.0)

@@ -162,13 +162,15 @@ def main():
                 a = rnd(M, K)
                 ws = [packw(N, K) for _ in range(4)]
                 out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
-                for fk in (7, 8):
+                from visualcla.weights import to_fragment_major
+                wfs = [to_fragment_major(w) for w in ws]
+                for fk, frag in ((7, False), (8, False), (8, True)):
                     def run():
-                        for w in ws:
-                            _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws)
+                        for w, wf in zip(ws, wfs):
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws, w_frag=wf if frag else None)
                     t = timeit(run, reps=10) / 4
-                    print(f"k{fk} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
-                del ws
+                    print(f"k{fk}{'f' if frag else ' '} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+                del ws, wfs
     if "gemv" in which:
         print("== GEMV (decode, weight streaming)")
         for M in (1, 4, 8):

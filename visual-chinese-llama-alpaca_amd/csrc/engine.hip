@@ -78,6 +78,7 @@ struct ResLayer {
 struct LlamaLayer {
     const float *ln1g, *ln2g;
     const void *wqkv, *wo, *wgu, *wd;
+    const void *wqkv_f, *wo_f, *wgu_f, *wd_f;   // optional fragment-major twins (batch decode)
 };
 
 struct vcla_ctx {
@@ -97,6 +98,7 @@ struct vcla_ctx {
     std::vector<LlamaLayer> llama;
     const float* norm_g = nullptr;
     const void* lm_head = nullptr;
+    const void* lm_head_f = nullptr;
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     int k_pad = 0;  // padded im2col width
     // cached decode graph
@@ -163,6 +165,18 @@ static int get_tensor(vcla_ctx* ctx, const std::string& name, size_t want_bytes,
     *out = it->second.ptr;
     return VCLA_OK;
 }
+
+// optional tensor: nullptr when absent, size-checked when present
+static int get_tensor_opt(vcla_ctx* ctx, const std::string& name, size_t want_bytes, const void** out) {
+    *out = nullptr;
+    if (ctx->tensors.find(name) == ctx->tensors.end()) return VCLA_OK;
+    return get_tensor(ctx, name, want_bytes, out);
+}
+#define GET_WF(dst, name, rows, cols)                                                                      \
+    do {                                                                                                   \
+        int _rc = get_tensor_opt(ctx, name, (size_t)pad_to(rows, 128) * (size_t)(cols) * 2, &dst);         \
+        if (_rc) return _rc;                                                                               \
+    } while (0)
 
 #define GET_W(dst, name, rows, cols)                                                                       \
     do {                                                                                                   \
@@ -236,9 +250,14 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
         GET_W(L.wo, p + "wo", c.t_hidden, c.t_hidden);
         GET_W(L.wgu, p + "wgu", 2 * c.t_inter, c.t_hidden);
         GET_W(L.wd, p + "wd", c.t_hidden, c.t_inter);
+        GET_WF(L.wqkv_f, p + "wqkv.f", 3 * c.t_hidden, c.t_hidden);
+        GET_WF(L.wo_f, p + "wo.f", c.t_hidden, c.t_hidden);
+        GET_WF(L.wgu_f, p + "wgu.f", 2 * c.t_inter, c.t_hidden);
+        GET_WF(L.wd_f, p + "wd.f", c.t_hidden, c.t_inter);
     }
     GET_F(ctx->norm_g, "llama.norm.g", c.t_hidden);
     GET_W(ctx->lm_head, "llama.lm_head", c.t_vocab, c.t_hidden);
+    GET_WF(ctx->lm_head_f, "llama.lm_head.f", c.t_vocab, c.t_hidden);
     const int d = c.t_hidden / c.t_heads;
     GET_F(ctx->rope_cos, "llama.rope_cos", (size_t)c.t_max_pos * (d / 2));
     GET_F(ctx->rope_sin, "llama.rope_sin", (size_t)c.t_max_pos * (d / 2));
@@ -329,7 +348,8 @@ static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry poin
 
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
-                int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f) {
+                int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f,
+                const void* w_frag = nullptr) {
     vcla_gemm_args a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32;
@@ -337,6 +357,7 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.force_kernel = 0;
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
     a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
+    a.W_frag = (M <= 128) ? w_frag : nullptr;
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
@@ -447,7 +468,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps));
     } else {
         RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE));
+        RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wqkv_f));
     }
     const float scale = 1.0f / sqrtf((float)d);
     if (T == 1) {
@@ -466,14 +487,14 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         a.Tk = pos0 + T;
         RUN(vcla_attention(&a, dt, s));
     }
-    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE));
+    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wo_f));
     if (fused) {
         RUN(gemm(ctx, s, w.x, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, L.ln2g, c.t_eps));
     } else {
         RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+        RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, nullptr, 0.f, L.wgu_f));
     }
-    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE));
+    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wd_f));
     return VCLA_OK;
 }
 
@@ -526,7 +547,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps));
     } else {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, ctx->lm_head_f));
     }
     if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
     if (advance_pos && pos_dev) {

@@ -427,7 +427,7 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
 // writes fp32 partial tiles to a workspace and gemm_panel_reduce_kernel applies the epilogue (fixed summation order).
 #define PN_BN 128
 #define PN_RING 4
-template <int EPI, typename OutT, int MT>
+template <int EPI, typename OutT, int MT, bool FRAG>
 __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
     constexpr int NA = (MT * 128 + 255) / 256;  // 16-byte A chunks per thread per K tile
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MT * 16 * 128];
@@ -455,13 +455,23 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
     const bf16_t *asrc0 = a_src(0), *asrc1 = a_src(1), *asrc2 = a_src(2), *asrc3 = a_src(3);
     const int adst0 = a_dst(0), adst1 = a_dst(1), adst2 = a_dst(2), adst3 = a_dst(3);
     // W fragment rows of this wave: 2 n-tiles; rows past N stay inside the 128-row padding, past n_pad are clamped
+    // FRAG: W_frag[n/16][k/32][lane][8] -- the fragment of (16-row tile, k-step) is 1 KiB contiguous, k-steps are adjacent:
+    //       this wave streams two fully contiguous regions; per-lane address = tile base + kstep * 512 + lane * 8 elements
     const bf16_t* wsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        int wr = n0 + wave * 32 + j * 16 + frow;
-        if (wr >= n_pad) wr = n_pad - 1;
-        wsrc[j] = Wg + (int64_t)wr * a.K + g * 8;
+        if (FRAG) {
+            int nt = (n0 + wave * 32 + j * 16) >> 4;
+            if (nt >= (n_pad >> 4)) nt = (n_pad >> 4) - 1;
+            wsrc[j] = (const bf16_t*)a.W_frag + ((int64_t)nt * (a.K / 32) + (int64_t)t_beg * 2) * 512 + lane * 8;
+        } else {
+            int wr = n0 + wave * 32 + j * 16 + frow;
+            if (wr >= n_pad) wr = n_pad - 1;
+            wsrc[j] = Wg + (int64_t)wr * a.K + g * 8;
+        }
     }
+    constexpr int WTILE = FRAG ? 1024 : GM_BK;   // elements between consecutive K tiles (64 k) in the W stream
+    constexpr int WSTEP = FRAG ? 512 : 32;       // elements between the two k-steps of a tile
     // 4-slot register ring, one named array per slot: slot indices must be literals for the compiler to keep the ring in
     // VGPRs (a ring indexed through a lambda parameter is demoted to scratch).
     struct AReg { u32x4_t c0, c1, c2, c3; };  // up to 4 chunks per thread; unused members are never touched (NA < 4)
@@ -477,7 +487,8 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
         if (NA >= 2) RA.c1 = *reinterpret_cast<const u32x4_t*>(asrc1 + ko_);                          \
         if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
-            const u32x4_t w_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc[q & 1] + ko_ + (q >> 1) * 32)); \
+            const u32x4_t w_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(                 \
+                wsrc[q & 1] + (int64_t)(valid_ ? (tile_) : nkc - 1) * WTILE + (q >> 1) * WSTEP));   \
             RW[q] = valid_ ? w_ : u32x4_t{0u, 0u, 0u, 0u};                                          \
         }                                                                                           \
     }
@@ -603,7 +614,8 @@ static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
     const int n_pad = (a->N + 127) / 128 * 128;
     const int splitk = panel_splitk(a, n_pad);
     dim3 grid((a->N + PN_BN - 1) / PN_BN, splitk);
-    gemm_panel_kernel<EPI, OutT, MT><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, true><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    else gemm_panel_kernel<EPI, OutT, MT, false><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     VCLA_CHECK_LAUNCH("gemm_panel_kernel");
     if (splitk > 1) {
         const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
@@ -1073,7 +1085,7 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
         else if (a->M <= 128) {
             // W streamed once.  Measured on MI355X (profiles/r01_kernel_microbench_run5.txt): the split-K panel kernel wins
             // for M >= 64, for short-N / long-K shapes (down-proj) and for N <= 4096 once M >= 32; else the skinny kernel
-            const bool panel = a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32)));
+            const bool panel = a->W_frag || (a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32))));
             kernel = panel ? 8 : 7;
         }
         else kernel = prefer_256(a) ? 4 : 1;
@@ -1085,6 +1097,7 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(!a->norm_gamma || kernel == 2 || kernel == 6, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
     VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
     VCLA_REQUIRE(!((kernel == 7 || kernel == 8) && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny / panel kernels need M <= 128 (got %d)", a->M);
+    VCLA_REQUIRE(!a->W_frag || (vcla_aligned(a->W_frag, 16) && a->K % 32 == 0), VCLA_ERR_BAD_ARG, "gemm: W_frag must be 16-byte aligned");
     VCLA_REQUIRE(!a->splitk_ws || vcla_aligned(a->splitk_ws, 16), VCLA_ERR_BAD_ARG, "gemm: splitk_ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {

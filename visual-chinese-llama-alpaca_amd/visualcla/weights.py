@@ -46,6 +46,33 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return torch.stack([gate.reshape(i // 16, 16, k), up.reshape(i // 16, 16, k)], dim=1).reshape(2 * i, k)
 
 
+def to_fragment_major(w_packed: torch.Tensor) -> torch.Tensor:
+    """[N_pad, K] (row-major, N_pad % 16 == 0, K % 32 == 0) -> [N_pad/16, K/32, 64, 8]: every MFMA operand fragment
+    (16 rows x 32 k of v_mfma_f32_16x16x32_bf16; lane = (k%32)//8 * 16 + n%16, 8 consecutive k per lane) is one contiguous
+    1 KiB block and the fragments of one 16-row tile are contiguous along K.  A wave that streams a tile's weights for
+    batch decode then reads one fully contiguous K/32-KiB region with plain 16-byte-per-lane loads (HBM page friendly),
+    straight into MFMA operand registers -- no LDS transpose."""
+    n, k = w_packed.shape
+    assert n % 16 == 0 and k % 32 == 0
+    return w_packed.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n // 16, k // 32, 64, 8)
+
+
+def from_fragment_major(wf: torch.Tensor) -> torch.Tensor:
+    nt, ks = wf.shape[0], wf.shape[1]
+    return wf.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().view(nt * 16, ks * 32)
+
+
+FRAG_KEYS = ("wqkv", "wo", "wgu", "wd")     # LLaMA decode matrices that get a fragment-major twin (".f")
+
+
+def add_fragment_copies(packed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Adds `llama.l{i}.{wqkv,wo,wgu,wd}.f` and `llama.lm_head.f` (second copy, ~13 GB at 7B: HBM is 288 GB)."""
+    for name in list(packed.keys()):
+        if name.startswith("llama.l") and name.rsplit(".", 1)[-1] in FRAG_KEYS or name == "llama.lm_head":
+            packed[name + ".f"] = to_fragment_major(packed[name])
+    return packed
+
+
 def rope_tables(max_pos: int, head_dim: int, theta: float):
     """fp32 cos/sin [max_pos, head_dim/2], computed exactly as hf:llama/modeling_llama.py:98-127 does (CPU, fp32)."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
@@ -132,6 +159,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg, device, act_dtype: torch.d
     theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
     cos, sin = rope_tables(t["max_position_embeddings"], hd, theta)
     out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
+    if act_dtype == torch.bfloat16:
+        add_fragment_copies(out)
     return out
 
 
@@ -194,6 +223,8 @@ def random_packed(cfg, device, act_dtype: torch.dtype, seed: int = 0) -> Dict[st
     theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
     cos, sin = rope_tables(t["max_position_embeddings"], hd, theta)
     out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
+    if act_dtype == torch.bfloat16:
+        add_fragment_copies(out)
     return out
 
 
