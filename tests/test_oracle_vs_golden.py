@@ -69,3 +69,23 @@ def test_kv_cache_decode_equals_full_forward():
     full = O.visualcla_forward(full_ids, px, torch.ones_like(full_ids), W, cfg)
     for s in range(3):
         assert torch.allclose(step_logits[s], full[:, ids.shape[1] - 1 + s], atol=1e-4)
+
+
+def test_position_embedding_extension():
+    """336-px support.  The reference's helper (models/visualcla/modeling_visualcla.py:13-43, unused by its scripts) cannot run
+    as written -- it reshapes with the PATCH COUNT where the grid side is meant (`grid_before = position_length_before - 1`,
+    :29,:33) -- so there is no reference output to pin; the intended semantics (keep the class row, bicubic-interpolate the
+    g x g grid, rebuild position_ids) are checked against the formula directly."""
+    from visualcla.weights import extend_position_embedding
+    g = torch.Generator().manual_seed(7)
+    pe = torch.randn(1 + 4 * 4, 8, generator=g)
+    sd = {"vision_model.vision_model.embeddings.position_embedding.weight": pe.clone(),
+          "vision_model.vision_model.embeddings.position_ids": torch.arange(17).unsqueeze(0)}
+    out = extend_position_embedding(sd, 14, 6 * 14)
+    new = out["vision_model.vision_model.embeddings.position_embedding.weight"]
+    want = torch.nn.functional.interpolate(pe[1:].reshape(4, 4, 8).permute(2, 0, 1)[None], size=(6, 6), mode="bicubic")[0]
+    assert new.shape == (37, 8) and torch.equal(new[0], pe[0])
+    assert torch.allclose(new[1:], want.permute(1, 2, 0).reshape(36, 8))
+    assert out["vision_model.vision_model.embeddings.position_ids"].shape == (1, 37)
+    same = extend_position_embedding({k: v.clone() for k, v in sd.items()}, 14, 6 * 14)   # idempotent at the target size
+    assert torch.equal(same["vision_model.vision_model.embeddings.position_embedding.weight"], new)

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .configuration_visualcla import VisualCLAConfig
-from .weights import pack_state_dict, random_packed, unpack_state_dict
+from .weights import extend_position_embedding, pack_state_dict, random_packed, unpack_state_dict  # noqa: F401
 
 
 def _act_dtype(torch_dtype) -> torch.dtype:
@@ -132,6 +132,7 @@ class VisualCLAModel:
     @classmethod
     def from_state_dict(cls, config: VisualCLAConfig, state_dict: Dict[str, torch.Tensor], device=None,
                         torch_dtype=torch.bfloat16) -> "VisualCLAModel":
+        _lib.require_device()          # fail loudly (no CPU fallback) before touching the device
         dev = torch.device(device if device is not None else "cuda:0")
         packed = pack_state_dict(state_dict, config, dev, _act_dtype(torch_dtype))
         return cls(config, packed, dev, torch_dtype)
@@ -273,6 +274,23 @@ class VisualCLAModel:
                     self._ws.clear()
                     with torch.cuda.device(dev):
                         self._build_ctx()
+        return self
+
+    def set_image_size(self, image_size: int):
+        """Re-target the vision tower to another input resolution (336 px -> 577 tokens): bicubic position-embedding
+        interpolation (reference helper semantics) + context rebuild.  Kernels are shape-generic in the token count."""
+        v = self.config.vision_config
+        if image_size == v["image_size"]:
+            return self
+        if image_size % v["patch_size"]:
+            raise ValueError(f"image_size {image_size} is not a multiple of the patch size {v['patch_size']}")
+        sd = self.state_dict()
+        extend_position_embedding(sd, v["patch_size"], image_size)
+        v["image_size"] = image_size
+        self.vision_model.config.image_size = image_size
+        self._packed = pack_state_dict(sd, self.config, self._device, self._dtype)
+        self._ws.clear()
+        self._build_ctx()
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:

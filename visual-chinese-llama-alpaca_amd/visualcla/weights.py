@@ -73,6 +73,27 @@ def add_fragment_copies(packed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
     return packed
 
 
+def extend_position_embedding(state_dict: Dict[str, torch.Tensor], patch_size: int, after: int) -> Dict[str, torch.Tensor]:
+    """Grow the CLIP position embedding for a larger input resolution (e.g. 224 -> 336 px, BASELINE configs[4]): the
+    class-token row is kept, the g x g patch grid is bicubically interpolated to (after // patch_size)^2, position_ids are
+    rebuilt.  In place.  This is the INTENDED behaviour of the reference helper of the same name
+    (models/visualcla/modeling_visualcla.py:13-43); that helper is dead code and cannot run as written (it reshapes with the
+    patch count instead of the grid side, :29/:33)."""
+    pe_key = next(k for k in state_dict if k.endswith("vision_model.embeddings.position_embedding.weight"))
+    pe = state_dict[pe_key]
+    n_before, dim = pe.shape
+    g0 = int(round((n_before - 1) ** 0.5))
+    g1 = after // patch_size
+    grid = pe[1:].reshape(g0, g0, dim).permute(2, 0, 1).unsqueeze(0).float()
+    grid = torch.nn.functional.interpolate(grid, size=(g1, g1), mode="bicubic")
+    new = torch.cat([pe[0:1].float(), grid.squeeze(0).permute(1, 2, 0).reshape(g1 * g1, dim)], dim=0).to(pe.dtype)
+    state_dict[pe_key] = new
+    for k in list(state_dict):
+        if k.endswith("vision_model.embeddings.position_ids"):
+            state_dict[k] = torch.arange(g1 * g1 + 1).unsqueeze(0)
+    return state_dict
+
+
 def rope_tables(max_pos: int, head_dim: int, theta: float):
     """fp32 cos/sin [max_pos, head_dim/2], computed exactly as hf:llama/modeling_llama.py:98-127 does (CPU, fp32)."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
