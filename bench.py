@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] weight path: fp8 (e4m3) decode weights, bf16 activations")
     ap.add_argument("--cpu-tokens", type=int, default=3, help="decode tokens in the bounded CPU sample")
     return ap.parse_args()
 
@@ -145,6 +146,8 @@ def main():
     model = visualcla.VisualCLAModel.from_random(cfg, device=dev, torch_dtype=torch.bfloat16, seed=0)
     model.tokenizer = stub_tokenizer(cfg_o)
     model.image_at_head = False
+    if args.fp8:
+        model.enable_fp8_decode()
 
     B = args.batch
     gB = B * world
@@ -205,14 +208,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (random-init 7B weights, N(0,1) 224x224 pixels, synthetic ids)",
+            "dtype": "bf16" if not args.fp8 else "bf16 activations / fp32 accumulate, fp8-e4m3 decode weights", "data": "synthetic (random-init 7B weights, N(0,1) 224x224 pixels, synthetic ids)",
             "config": {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU, prompt T={args.prompt_len} with 64 image tokens, "
                                     f"{args.new_tokens}-token greedy decode (BASELINE configs[{1 if B == 1 else 2}])"),
                        "global_batch": gB, "seq_len": args.prompt_len, "new_tokens": args.new_tokens,
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"},
         }
         res["breakdown_ms"] = breakdown
-        res["roofline"] = gemv_roofline(model)
+        res["roofline"] = gemv_roofline(model) if not args.fp8 else None
         if not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(model, cfg_o, args.prompt_len, args.new_tokens, args.cpu_tokens)

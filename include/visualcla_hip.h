@@ -122,6 +122,12 @@ typedef struct vcla_gemm_args {
     /* optional fragment-major twin of W, [N_pad/16][K/32][64 lanes][8] bf16 (visualcla/weights.py:to_fragment_major):
        lets the M <= 128 panel kernel stream each 16-row tile as one contiguous region */
     const void* W_frag;
+    /* optional OCP fp8 (e4m3fn) weight copies for the HBM-bound decode kernels, per-row fp32 scale w_scale [N_pad]
+       (W ~= q * w_scale[row]); W_q8: [N_pad, K] row-major (M = 1 GEMV); W_q8_frag: [N_pad/16][K/64][64 lanes][16]
+       (two MFMA k-steps per 16-byte lane load; panel kernel).  Dequantised to bf16 in registers; fp32 accumulate. */
+    const void* W_q8;
+    const void* W_q8_frag;
+    const float* w_scale;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

@@ -463,3 +463,30 @@ def test_gemv1_f32_out_bias_residual(lib):
                        force_kernel=fk, norm_gamma=gamma.to(DEV), norm_eps=1e-6)
         assert got.dtype == torch.float32
         _cmp(f"gemv1_full[k{fk}]", got, ref, atol=2e-4, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ fp8 (e4m3fn) decode weights
+@pytest.mark.parametrize("M,N,K,epi", [(1, 4096, 512, 0), (1, 2048, 1408, 3), (1, 1000, 4096, 0), (2, 512, 4096, 0), (16, 4096, 1408, 3),
+                                       (64, 320, 640, 0), (128, 288, 2048, 3)])
+def test_gemm_fp8_weights(lib, M, N, K, epi):
+    """the kernels must compute exactly the function of the DEQUANTISED weights (fp8 -> bf16 is exact), fp32 accumulate"""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows, to_fragment_pair_major_fp8
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    gamma = bf16r(1 + 0.1 * torch.randn(K, generator=g))
+    wp = _pack(w)
+    q, sc = quantize_fp8_rows(wp)
+    wdq = dequantize_fp8_rows(q, sc)[:N].cpu()
+    assert (wdq - w).abs().max() <= 0.07 * w.abs().max()          # e4m3: 3 mantissa bits
+    use_norm = M == 1
+    h = O.llama_rmsnorm(a, gamma, 1e-6) if use_norm else a
+    res = bf16r(torch.randn(M, N // 2 if epi == 3 else N, generator=g))
+    ref = _gemm_ref(h, wdq, None, epi, res)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    got = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, residual=res.to(DEV, torch.bfloat16), epilogue=epi, splitk_ws=ws,
+                   w_q8=q, w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc,
+                   norm_gamma=gamma.to(DEV) if use_norm else None, norm_eps=1e-6)
+    _cmp(f"gemm_fp8[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=8e-3)

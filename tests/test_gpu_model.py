@@ -185,6 +185,37 @@ def test_state_dict_roundtrip_and_dtype_switch():
     assert (b - ref).abs().max().item() <= 1e-3 and (a - ref).abs().max().item() <= 6e-2
 
 
+def test_fp8_decode_weights_match_oracle_on_dequantised_weights(golden_dir):
+    """BASELINE configs[4] weight path: with fp8 copies enabled the model must equal the oracle evaluated on the
+    DEQUANTISED LLaMA matrices (tolerance of the bf16 mode), and stay close to the unquantised reference."""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows, pad_to
+    g, cfg, W, px, ids, mask, n_new = _setup("small_b2", golden_dir)
+    m = make_hip_model(cfg, W, torch.bfloat16)
+    m.enable_fp8_decode()
+    assert m.fp8_decode
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.cpu()
+    Wq = dict(W)
+    for k, v in W.items():
+        if k.startswith("text_model.") and v.dim() == 2 and "embed_tokens" not in k:
+            wp = torch.zeros(pad_to(v.shape[0], 128), v.shape[1])
+            wp[: v.shape[0]] = v
+            q, sc = quantize_fp8_rows(wp.to(torch.bfloat16))
+            Wq[k] = dequantize_fp8_rows(q, sc)[: v.shape[0]]
+    ref_q = O.visualcla_forward(ids, px, mask, Wq, cfg)
+    err = (out - ref_q).abs()
+    _report(f"fp8 small_b2 logits vs oracle-on-dequantised: max {err.max().item():.3e} mean {err.mean().item():.3e}")
+    assert err.max().item() <= 6e-2 and err.mean().item() <= 1e-2
+    ref = torch.from_numpy(g["logits"])
+    drift = (out - ref).abs()
+    _report(f"fp8 small_b2 logits vs unquantised reference: max {drift.max().item():.3e} mean {drift.mean().item():.3e}")
+    assert drift.mean().item() <= 5e-2          # quantisation noise itself (e4m3, per-row scale), reported not hidden
+    toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=4, do_sample=False,
+                      eos_token_id=None)
+    assert toks.shape == (2, 4)
+    m.enable_fp8_decode(False)
+    assert not m.fp8_decode
+
+
 # ------------------------------------------------------------------ full VisualCLA-7B geometry: properties
 @pytest.fixture(scope="module")
 def model_7b():

@@ -75,10 +75,17 @@ struct ResLayer {
     const float *bq, *bkv, *bo, *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
     const void *wq, *wkv, *wo, *w1, *w2;
 };
+// optional alternative copies of one weight matrix for the M <= 128 (decode) kernels
+struct WVar {
+    const void* frag = nullptr;   // bf16 fragment-major twin                    ("<name>.f")
+    const void* q8 = nullptr;     // fp8 e4m3fn row-major                        ("<name>.q8")
+    const void* q8f = nullptr;    // fp8 fragment-pair-major                     ("<name>.q8f")
+    const float* s8 = nullptr;    // per-row fp32 scale of the fp8 copies         ("<name>.s8")
+};
 struct LlamaLayer {
     const float *ln1g, *ln2g;
     const void *wqkv, *wo, *wgu, *wd;
-    const void *wqkv_f, *wo_f, *wgu_f, *wd_f;   // optional fragment-major twins (batch decode)
+    WVar vqkv, vo, vgu, vd;
 };
 
 struct vcla_ctx {
@@ -98,7 +105,7 @@ struct vcla_ctx {
     std::vector<LlamaLayer> llama;
     const float* norm_g = nullptr;
     const void* lm_head = nullptr;
-    const void* lm_head_f = nullptr;
+    WVar vlm;
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     int k_pad = 0;  // padded im2col width
     // cached decode graph
@@ -172,10 +179,22 @@ static int get_tensor_opt(vcla_ctx* ctx, const std::string& name, size_t want_by
     if (ctx->tensors.find(name) == ctx->tensors.end()) return VCLA_OK;
     return get_tensor(ctx, name, want_bytes, out);
 }
-#define GET_WF(dst, name, rows, cols)                                                                      \
-    do {                                                                                                   \
-        int _rc = get_tensor_opt(ctx, name, (size_t)pad_to(rows, 128) * (size_t)(cols) * 2, &dst);         \
-        if (_rc) return _rc;                                                                               \
+static int get_variants(vcla_ctx* ctx, const std::string& name, int rows, int cols, WVar* v) {
+    const size_t np = (size_t)pad_to(rows, 128);
+    const void* s8 = nullptr;
+    int rc = get_tensor_opt(ctx, name + ".f", np * cols * 2, &v->frag);
+    if (!rc) rc = get_tensor_opt(ctx, name + ".q8", np * cols, &v->q8);
+    if (!rc) rc = get_tensor_opt(ctx, name + ".q8f", np * cols, &v->q8f);
+    if (!rc) rc = get_tensor_opt(ctx, name + ".s8", np * 4, &s8);
+    v->s8 = (const float*)s8;
+    if (!rc && (v->q8 || v->q8f) && !(v->q8 && v->q8f && v->s8))
+        return vcla_fail(VCLA_ERR_MISSING_TENSOR, "fp8 copies of '%s' need all of .q8, .q8f and .s8", name.c_str());
+    return rc;
+}
+#define GET_WF(dst, name, rows, cols)                             \
+    do {                                                          \
+        int _rc = get_variants(ctx, name, rows, cols, &dst);      \
+        if (_rc) return _rc;                                      \
     } while (0)
 
 #define GET_W(dst, name, rows, cols)                                                                       \
@@ -250,14 +269,14 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
         GET_W(L.wo, p + "wo", c.t_hidden, c.t_hidden);
         GET_W(L.wgu, p + "wgu", 2 * c.t_inter, c.t_hidden);
         GET_W(L.wd, p + "wd", c.t_hidden, c.t_inter);
-        GET_WF(L.wqkv_f, p + "wqkv.f", 3 * c.t_hidden, c.t_hidden);
-        GET_WF(L.wo_f, p + "wo.f", c.t_hidden, c.t_hidden);
-        GET_WF(L.wgu_f, p + "wgu.f", 2 * c.t_inter, c.t_hidden);
-        GET_WF(L.wd_f, p + "wd.f", c.t_hidden, c.t_inter);
+        GET_WF(L.vqkv, p + "wqkv", 3 * c.t_hidden, c.t_hidden);
+        GET_WF(L.vo, p + "wo", c.t_hidden, c.t_hidden);
+        GET_WF(L.vgu, p + "wgu", 2 * c.t_inter, c.t_hidden);
+        GET_WF(L.vd, p + "wd", c.t_hidden, c.t_inter);
     }
     GET_F(ctx->norm_g, "llama.norm.g", c.t_hidden);
     GET_W(ctx->lm_head, "llama.lm_head", c.t_vocab, c.t_hidden);
-    GET_WF(ctx->lm_head_f, "llama.lm_head.f", c.t_vocab, c.t_hidden);
+    GET_WF(ctx->vlm, "llama.lm_head", c.t_vocab, c.t_hidden);
     const int d = c.t_hidden / c.t_heads;
     GET_F(ctx->rope_cos, "llama.rope_cos", (size_t)c.t_max_pos * (d / 2));
     GET_F(ctx->rope_sin, "llama.rope_sin", (size_t)c.t_max_pos * (d / 2));
@@ -349,7 +368,7 @@ static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry poin
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
                 int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f,
-                const void* w_frag = nullptr) {
+                const WVar* wv = nullptr) {
     vcla_gemm_args a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32;
@@ -357,7 +376,10 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.force_kernel = 0;
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
     a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
-    a.W_frag = (M <= 128) ? w_frag : nullptr;
+    if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)
+        if (wv->q8 && wv->q8f && wv->s8) { a.W_q8 = wv->q8; a.W_q8_frag = wv->q8f; a.w_scale = wv->s8; }
+        else a.W_frag = wv->frag;
+    }
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
@@ -465,10 +487,10 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
     const bool fused = (dt == VCLA_F32) ? (M <= 8) : (M == 1);  // must mirror vcla_gemm's kernel choice
     if (fused) {
-        RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps));
+        RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps, &L.vqkv));
     } else {
         RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wqkv_f));
+        RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vqkv));
     }
     const float scale = 1.0f / sqrtf((float)d);
     if (T == 1) {
@@ -487,14 +509,14 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         a.Tk = pos0 + T;
         RUN(vcla_attention(&a, dt, s));
     }
-    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wo_f));
+    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vo));
     if (fused) {
-        RUN(gemm(ctx, s, w.x, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, L.ln2g, c.t_eps));
+        RUN(gemm(ctx, s, w.x, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, L.ln2g, c.t_eps, &L.vgu));
     } else {
         RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, nullptr, 0.f, L.wgu_f));
+        RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, nullptr, 0.f, &L.vgu));
     }
-    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, L.wd_f));
+    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vd));
     return VCLA_OK;
 }
 
@@ -544,10 +566,10 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask));
     float* lg = logits ? logits : w.logits;
     if ((dt == VCLA_F32) ? (B <= 8) : (B == 1)) {
-        RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps));
+        RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps, &ctx->vlm));
     } else {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, ctx->lm_head_f));
+        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
     }
     if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
     if (advance_pos && pos_dev) {

@@ -53,6 +53,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
+                    if (a.w_scale) { gt *= a.w_scale[np_ + r]; up *= a.w_scale[np_ + 16 + r]; }
                     if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
                     v[r] = act_silu(gt) * up;
                 }
@@ -61,6 +62,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[i][j][r];
+                    if (a.w_scale) x *= a.w_scale[n + r];   // n + r < N_pad always
                     if (a.bias && n + r < a.N) x += a.bias[n + r];
                     v[r] = epi_act<EPI>(x);
                 }
@@ -427,7 +429,17 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
 // writes fp32 partial tiles to a workspace and gemm_panel_reduce_kernel applies the epilogue (fixed summation order).
 #define PN_BN 128
 #define PN_RING 4
-template <int EPI, typename OutT, int MT, bool FRAG>
+// 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    const u32x4_t p = {pack_bf2(a.x, a.y), pack_bf2(b.x, b.y), pack_bf2(c.x, c.y), pack_bf2(d.x, d.y)};
+    return __builtin_bit_cast(bf16x8_t, p);
+}
+
+// WMODE: 0 = W row-major bf16, 1 = fragment-major bf16 (W_frag), 2 = fragment-pair-major fp8 (W_q8_frag + w_scale)
+template <int EPI, typename OutT, int MT, int WMODE>
 __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
     constexpr int NA = (MT * 128 + 255) / 256;  // 16-byte A chunks per thread per K tile
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MT * 16 * 128];
@@ -460,18 +472,24 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
     const bf16_t* wsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        if (FRAG) {
+        if (WMODE == 1) {
             int nt = (n0 + wave * 32 + j * 16) >> 4;
             if (nt >= (n_pad >> 4)) nt = (n_pad >> 4) - 1;
             wsrc[j] = (const bf16_t*)a.W_frag + ((int64_t)nt * (a.K / 32) + (int64_t)t_beg * 2) * 512 + lane * 8;
+        } else if (WMODE == 2) {
+            // fp8: one 1 KiB block per (16-row tile, 64 k); pointer arithmetic in bf16_t units (2 bytes)
+            int nt = (n0 + wave * 32 + j * 16) >> 4;
+            if (nt >= (n_pad >> 4)) nt = (n_pad >> 4) - 1;
+            wsrc[j] = (const bf16_t*)a.W_q8_frag + ((int64_t)nt * (a.K / 64) + (int64_t)t_beg) * 512 + lane * 8;
         } else {
             int wr = n0 + wave * 32 + j * 16 + frow;
             if (wr >= n_pad) wr = n_pad - 1;
             wsrc[j] = Wg + (int64_t)wr * a.K + g * 8;
         }
     }
-    constexpr int WTILE = FRAG ? 1024 : GM_BK;   // elements between consecutive K tiles (64 k) in the W stream
-    constexpr int WSTEP = FRAG ? 512 : 32;       // elements between the two k-steps of a tile
+    constexpr int WTILE = WMODE == 1 ? 1024 : (WMODE == 2 ? 512 : GM_BK);  // bf16_t units between consecutive K tiles
+    constexpr int WSTEP = WMODE == 1 ? 512 : 32;                           // ... between the two k-steps of a tile
+    constexpr int NWL = WMODE == 2 ? 2 : 4;                                // 16-byte weight loads per lane per K tile
     // 4-slot register ring, one named array per slot: slot indices must be literals for the compiler to keep the ring in
     // VGPRs (a ring indexed through a lambda parameter is demoted to scratch).
     struct AReg { u32x4_t c0, c1, c2, c3; };  // up to 4 chunks per thread; unused members are never touched (NA < 4)
@@ -486,7 +504,7 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
         RA.c0 = *reinterpret_cast<const u32x4_t*>(asrc0 + ko_);                                       \
         if (NA >= 2) RA.c1 = *reinterpret_cast<const u32x4_t*>(asrc1 + ko_);                          \
         if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        _Pragma("unroll") for (int q = 0; q < NWL; ++q) {                                           \
             const u32x4_t w_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(                 \
                 wsrc[q & 1] + (int64_t)(valid_ ? (tile_) : nkc - 1) * WTILE + (q >> 1) * WSTEP));   \
             RW[q] = valid_ ? w_ : u32x4_t{0u, 0u, 0u, 0u};                                          \
@@ -501,8 +519,14 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
 #define PN_COMPUTE(RW, cur_)                                                                        \
     {                                                                                               \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
-            const bf16x8_t w0_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 0]);                      \
-            const bf16x8_t w1_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 1]);                      \
+            bf16x8_t w0_, w1_;                                                                      \
+            if (WMODE == 2) { /* RW[j] = 16 fp8 of n-tile j: .xy -> k-step 0, .zw -> k-step 1 */    \
+                w0_ = kk == 0 ? fp8x8_to_bf16x8(RW[0].x, RW[0].y) : fp8x8_to_bf16x8(RW[0].z, RW[0].w); \
+                w1_ = kk == 0 ? fp8x8_to_bf16x8(RW[1].x, RW[1].y) : fp8x8_to_bf16x8(RW[1].z, RW[1].w); \
+            } else {                                                                                \
+                w0_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 0]);                                 \
+                w1_ = __builtin_bit_cast(bf16x8_t, RW[kk * 2 + 1]);                                 \
+            }                                                                                       \
             _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                        \
                 const bf16x8_t af_ = *reinterpret_cast<const bf16x8_t*>(&As[cur_][lds_off(i * 16 + frow, kk * 4 + g)]); \
                 acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0_, af_, acc[i][0], 0, 0, 0);  \
@@ -570,6 +594,7 @@ __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(vcla_gemm_args a
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (a.w_scale) { gt[r] *= a.w_scale[np_ + r]; up[r] *= a.w_scale[np_ + 16 + r]; }
             if (a.bias) { gt[r] += a.bias[np_ + r]; up[r] += a.bias[np_ + 16 + r]; }
             v[r] = act_silu(gt[r]) * up[r];
         }
@@ -582,6 +607,7 @@ __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(vcla_gemm_args a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float x = sacc[r];
+            if (a.w_scale) x *= a.w_scale[n + r];
             if (a.bias && n + r < a.N) x += a.bias[n + r];
             v[r] = epi_act<EPI>(x);
         }
@@ -614,8 +640,9 @@ static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
     const int n_pad = (a->N + 127) / 128 * 128;
     const int splitk = panel_splitk(a, n_pad);
     dim3 grid((a->N + PN_BN - 1) / PN_BN, splitk);
-    if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, true><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
-    else gemm_panel_kernel<EPI, OutT, MT, false><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    if (a->W_q8_frag) gemm_panel_kernel<EPI, OutT, MT, 2><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    else if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, 1><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+    else gemm_panel_kernel<EPI, OutT, MT, 0><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     VCLA_CHECK_LAUNCH("gemm_panel_kernel");
     if (splitk > 1) {
         const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
@@ -881,6 +908,136 @@ __global__ __launch_bounds__(WPB * 64) void gemv1_kernel(vcla_gemm_args a) {
     }
 }
 
+// fp8 (e4m3fn) weights, per-row scale: the same streaming structure with HALF the bytes per weight element.
+// lane loads 16 B = 16 weights; 8 v_cvt_pk_f32_fp8 per load; the row scale is applied once after the reduction.
+template <int R, int U, int WPB, bool SWIGLU, typename OutT>
+__global__ __launch_bounds__(WPB * 64) void gemv1_fp8_kernel(vcla_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [K]
+    __shared__ float red[WPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave;
+    const bf16_t* X = (const bf16_t*)a.A;
+    const bool fused_norm = a.norm_gamma != nullptr;
+    float rstd = 1.f;
+    {
+        float ss = 0.f;
+        for (int k = threadIdx.x * 8; k < a.K; k += WPB * 64 * 8) {
+            float xv[8];
+            bf8_to_f32(*reinterpret_cast<const uint4*>(X + k), xv);
+            if (fused_norm) {
+                const float4 g0 = *reinterpret_cast<const float4*>(a.norm_gamma + k);
+                const float4 g1 = *reinterpret_cast<const float4*>(a.norm_gamma + k + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ss += xv[e] * xv[e]; xv[e] *= gm[e]; }
+            }
+            *reinterpret_cast<float4*>(xs + k) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            *reinterpret_cast<float4*>(xs + k + 4) = make_float4(xv[4], xv[5], xv[6], xv[7]);
+        }
+        if (fused_norm) {
+            ss = wave_sum(ss);
+            if (lane == 0) red[wave] = ss;
+        }
+        __syncthreads();
+        if (fused_norm) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) tot += red[w];
+            rstd = rsqrtf(tot / (float)a.K + a.norm_eps);
+        }
+    }
+    constexpr int P = SWIGLU ? R / 2 : R;
+    const int n_out = SWIGLU ? a.N / 2 : a.N;
+    if (gw * P >= n_out) return;
+    int rows[R];
+    if (SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int j = gw * P + r;
+            rows[r] = (j >> 4) * 32 + (j & 15);
+            rows[r + P] = rows[r] + 16;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rows[r] = gw * R + r;
+    }
+    const unsigned char* Wq = (const unsigned char*)a.W_q8;
+    const unsigned char* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wp[r] = Wq + (int64_t)rows[r] * a.K;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    for (int k0 = lane * 16; k0 < a.K; k0 += 1024 * U) {
+        u32x4_t w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 1024;
+            if (k < a.K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp[r] + k));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 1024;
+            if (k < a.K) {
+                float xv[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(xs + k + q * 4);
+                    xv[q * 4] = t.x; xv[q * 4 + 1] = t.y; xv[q * 4 + 2] = t.z; xv[q * 4 + 3] = t.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t d[4] = {w[u][r].x, w[u][r].y, w[u][r].z, w[u][r].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(d[q], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(d[q], true);
+                        acc[r] += lo.x * xv[q * 4] + lo.y * xv[q * 4 + 1] + hi.x * xv[q * 4 + 2] + hi.y * xv[q * 4 + 3];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]) * rstd * a.w_scale[rows[r]];
+    OutT* Cg = (OutT*)a.C + remap_row(a, 0) * a.ldc;
+    if (SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < P; ++r)
+            if (lane == r) {
+                float gt = acc[r], up = acc[r + P];
+                if (a.bias) { gt += a.bias[rows[r]]; up += a.bias[rows[r + P]]; }
+                float v = act_silu(gt) * up;
+                const int n = gw * P + r;
+                if (a.residual) v += bf2f(((const bf16_t*)a.residual)[n]);
+                Act<OutT>::st(Cg + n, v);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (lane == r && rows[r] < a.N) {
+                float v = acc[r];
+                if (a.bias) v += a.bias[rows[r]];
+                if (a.residual) v += bf2f(((const bf16_t*)a.residual)[rows[r]]);
+                Act<OutT>::st(Cg + rows[r], v);
+            }
+    }
+}
+
+template <int R, bool SWIGLU, typename OutT>
+static int launch_gemv1_fp8(const vcla_gemm_args* a, hipStream_t s) {
+    constexpr int WPB = 8, U = 4;
+    constexpr int P = SWIGLU ? R / 2 : R;
+    const int n_out = SWIGLU ? a->N / 2 : a->N;
+    const int waves = (n_out + P - 1) / P;
+    gemv1_fp8_kernel<R, U, WPB, SWIGLU, OutT><<<(waves + WPB - 1) / WPB, WPB * 64, (size_t)a->K * 4, s>>>(*a);
+    VCLA_CHECK_LAUNCH("gemv1_fp8_kernel");
+    return VCLA_OK;
+}
+
 template <int R, bool SWIGLU, typename OutT>
 static int launch_gemv1(const vcla_gemm_args* a, hipStream_t s) {
     constexpr int WPB = 8, U = 4;
@@ -898,6 +1055,11 @@ static bool gemv1_applicable(const vcla_gemm_args* a, int dtype) {
     return dtype == VCLA_BF16 && a->M == 1 && a->K <= 15360 && (a->epilogue == VCLA_EPI_NONE || a->epilogue == VCLA_EPI_SWIGLU);
 }
 static int launch_gemv1_auto(const vcla_gemm_args* a, hipStream_t s) {
+    if (a->W_q8 && a->w_scale) {   // fp8 weight copy present: half the HBM bytes
+        if (a->epilogue == VCLA_EPI_SWIGLU)
+            return a->out_f32 ? launch_gemv1_fp8<2, true, float>(a, s) : launch_gemv1_fp8<2, true, bf16_t>(a, s);
+        return a->out_f32 ? launch_gemv1_fp8<2, false, float>(a, s) : launch_gemv1_fp8<2, false, bf16_t>(a, s);
+    }
     if (a->epilogue == VCLA_EPI_SWIGLU)
         return a->out_f32 ? launch_gemv1<2, true, float>(a, s) : launch_gemv1<2, true, bf16_t>(a, s);
     if (a->N >= 16384)  // very tall (lm_head): 2 rows per wave halves the per-workgroup x staging
@@ -1085,7 +1247,7 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
         else if (a->M <= 128) {
             // W streamed once.  Measured on MI355X (profiles/r01_kernel_microbench_run5.txt): the split-K panel kernel wins
             // for M >= 64, for short-N / long-K shapes (down-proj) and for N <= 4096 once M >= 32; else the skinny kernel
-            const bool panel = a->W_frag || (a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32))));
+            const bool panel = a->W_frag || a->W_q8_frag || (a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32))));
             kernel = panel ? 8 : 7;
         }
         else kernel = prefer_256(a) ? 4 : 1;
@@ -1098,6 +1260,14 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
     VCLA_REQUIRE(!((kernel == 7 || kernel == 8) && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny / panel kernels need M <= 128 (got %d)", a->M);
     VCLA_REQUIRE(!a->W_frag || (vcla_aligned(a->W_frag, 16) && a->K % 32 == 0), VCLA_ERR_BAD_ARG, "gemm: W_frag must be 16-byte aligned");
+    VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
+                 "gemm: fp8 weights need w_scale and bf16 activations");
+    VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
+    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8, VCLA_ERR_BAD_ARG,
+                 "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8) and the M <= 128 panel kernel (needs W_q8_frag)");
+    VCLA_REQUIRE(!(kernel == 2 && a->w_scale) || (a->W_q8 && gemv1_applicable(a, dtype)), VCLA_ERR_BAD_ARG,
+                 "gemm: fp8 GEMV needs W_q8, M = 1, bf16, epilogue NONE/SWIGLU");
+    VCLA_REQUIRE(!(kernel == 8 && a->w_scale) || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: fp8 panel kernel needs W_q8_frag");
     VCLA_REQUIRE(!a->splitk_ws || vcla_aligned(a->splitk_ws, 16), VCLA_ERR_BAD_ARG, "gemm: splitk_ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("norm_gamma", C.c_void_p), ("norm_eps", C.c_float),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
         ("W_frag", C.c_void_p),
+        ("W_q8", C.c_void_p), ("W_q8_frag", C.c_void_p), ("w_scale", C.c_void_p),
     ]
 
 
@@ -175,7 +176,7 @@ def rmsnorm(x, gamma, eps, out=None):
 
 
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
-         group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None):
+         group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out]."""
     lib = load()
     M, K = a.shape
@@ -194,6 +195,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args.force_kernel = force_kernel
     args.norm_gamma, args.norm_eps = ptr(norm_gamma), float(norm_eps)
     args.W_frag = ptr(w_frag)
+    args.W_q8, args.W_q8_frag, args.w_scale = ptr(w_q8), ptr(w_q8_frag), ptr(w_scale)
     args.splitk_ws = ptr(splitk_ws)
     args.splitk_ws_bytes = splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0
     check(lib.vcla_gemm(C.byref(args), dtype_code(a.dtype), stream_ptr()))

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .configuration_visualcla import VisualCLAConfig
-from .weights import extend_position_embedding, pack_state_dict, random_packed, unpack_state_dict  # noqa: F401
+from .weights import add_fp8_copies, extend_position_embedding, pack_state_dict, random_packed, unpack_state_dict  # noqa: F401
 
 
 def _act_dtype(torch_dtype) -> torch.dtype:
@@ -275,6 +275,27 @@ class VisualCLAModel:
                     with torch.cuda.device(dev):
                         self._build_ctx()
         return self
+
+    def enable_fp8_decode(self, enabled: bool = True):
+        """BASELINE configs[4] weight path: OCP fp8 (e4m3fn, per-row scale) copies of the LLaMA projection / lm_head
+        matrices for the HBM-bound decode kernels (M <= 128); prefill tiles and the vision stack stay bf16.  The MI355X
+        analogue of the reference's `load_in_8bit` (bitsandbytes on the LLaMA only, modeling_visualcla.py:155)."""
+        if self._dtype != torch.bfloat16:
+            raise ValueError("fp8 decode weights need the bf16 activation mode")
+        has = any(k.endswith(".q8") for k in self._packed)
+        if enabled and not has:
+            add_fp8_copies(self._packed)
+        elif not enabled and has:
+            for k in [k for k in self._packed if k.endswith((".q8", ".q8f", ".s8"))]:
+                del self._packed[k]
+        else:
+            return self
+        self._build_ctx()
+        return self
+
+    @property
+    def fp8_decode(self) -> bool:
+        return any(k.endswith(".q8") for k in self._packed)
 
     def set_image_size(self, image_size: int):
         """Re-target the vision tower to another input resolution (336 px -> 577 tokens): bicubic position-embedding

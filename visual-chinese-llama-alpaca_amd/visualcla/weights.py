@@ -62,6 +62,36 @@ def from_fragment_major(wf: torch.Tensor) -> torch.Tensor:
     return wf.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().view(nt * 16, ks * 32)
 
 
+def quantize_fp8_rows(w_packed: torch.Tensor):
+    """bf16 [N_pad, K] -> (uint8 [N_pad, K] holding OCP e4m3fn bits, fp32 per-row scale [N_pad]); W ~= q * scale[row]."""
+    wf = w_packed.float()
+    scale = (wf.abs().amax(dim=1) / 448.0).clamp_min(1e-20)
+    q = (wf / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.float().contiguous()
+
+
+def dequantize_fp8_rows(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None].float()
+
+
+def to_fragment_pair_major_fp8(q: torch.Tensor) -> torch.Tensor:
+    """uint8 [N_pad, K] -> [N_pad/16, K/64, 64, 16]: lane (k%32)//8*16 + n%16 holds 8 elements of k-step 2j then 8 of
+    k-step 2j+1 -> one 16-byte load per lane feeds two MFMA k-steps; a 16-row tile is contiguous along K."""
+    n, k = q.shape
+    assert n % 16 == 0 and k % 64 == 0
+    return q.view(n // 16, 16, k // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous().view(n // 16, k // 64, 64, 16)
+
+
+def add_fp8_copies(packed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """fp8 twins of the LLaMA decode matrices: `<name>.q8` (row-major), `<name>.q8f` (fragment-pair-major), `<name>.s8`."""
+    for name in list(packed.keys()):
+        if (name.startswith("llama.l") and name.rsplit(".", 1)[-1] in FRAG_KEYS) or name == "llama.lm_head":
+            q, sc = quantize_fp8_rows(packed[name])
+            packed[name + ".q8"], packed[name + ".s8"] = q, sc
+            packed[name + ".q8f"] = to_fragment_pair_major_fp8(q)
+    return packed
+
+
 FRAG_KEYS = ("wqkv", "wo", "wgu", "wd")     # LLaMA decode matrices that get a fragment-major twin (".f")
 
 
