@@ -20,4 +20,14 @@ if [ "$mode" != "quick" ]; then
   echo "== rocprof"; rm -rf gpurun_out/prof; cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3
   cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*.csv" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"; find gpurun_out/prof -name "*kernel_trace.csv" -delete
 fi
+if [ "$mode" = "pmc" ] || [ "$mode" = "full" ]; then
+  echo "== PMC (HBM traffic of the dominant kernel; separate passes, counters only)"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_gemv.py 2>&1 | tail -2)
+    f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" $c | tee gpurun_out/pmc_$c.txt
+    find gpurun_out/pmc_$c -name "*.csv" -size +2M -delete
+  done
+fi
 echo "== done"

@@ -102,25 +102,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) qreg[e] = qs[kc_ * 8 + e];
     float mx = -INFINITY;
-    for (int j0 = wave * KPW; j0 < Tk; j0 += 4 * KPW) {
-        const int j = j0 + ksub;
-        float part_dot = 0.f;
-        if (j < pos) {
-            float kv[8];
-            load8<T>(kbase + (int64_t)j * D + kc_ * 8, kv);
+    constexpr int UK = 4;  // independent key groups per iteration: 4 row loads in flight before the shuffle reductions
+    for (int j0 = wave * KPW; j0 < Tk; j0 += 4 * KPW * UK) {
+        float pd[UK];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part_dot += qreg[e] * kv[e];
-        } else if (j == pos) {
+        for (int u = 0; u < UK; ++u) {
+            const int j = j0 + u * 4 * KPW + ksub;
+            pd[u] = 0.f;
+            if (j < pos) {
+                float kv[8];
+                load8<T>(kbase + (int64_t)j * D + kc_ * 8, kv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part_dot += qreg[e] * knew[kc_ * 8 + e];
+                for (int e = 0; e < 8; ++e) pd[u] += qreg[e] * kv[e];
+            } else if (j == pos) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pd[u] += qreg[e] * knew[kc_ * 8 + e];
+            }
         }
 #pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
-        if (j < Tk) {
-            float sv = scale * part_dot;
-            if (km && km[j] == 0) sv = -INFINITY;
-            if (kc_ == 0) sc[j] = sv;
-            mx = fmaxf(mx, sv);
+        for (int u = 0; u < UK; ++u) {
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) pd[u] += __shfl_xor(pd[u], off, 64);
+            const int j = j0 + u * 4 * KPW + ksub;
+            if (j < Tk) {
+                float sv = scale * pd[u];
+                if (km && km[j] == 0) sv = -INFINITY;
+                if (kc_ == 0) sc[j] = sv;
+                mx = fmaxf(mx, sv);
+            }
         }
     }
     mx = wave_max(mx);
