@@ -81,9 +81,22 @@ def gemv_roofline(model, n_rep: int = 20):
     launches = n_rep * layers
     avg_us = total_ms * 1e3 / launches
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,M=1,EPI_SWIGLU,R=4> (gate/up + fused RMSNorm)",
+    # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE doubled
+    # per the gfx950 correction; tools/gpu_check.sh pmc -> profiles/r01_pmc_gemv1_*.txt).  Not collectable inside this run.
+    traffic, src = None, None
+    try:
+        import re
+        tot = 0.0
+        for nm in ("fetch_size", "write_size"):
+            m = re.search(r"-> ([0-9.]+) MB per launch", open(os.path.join(ROOT, "profiles", f"r01_pmc_gemv1_{nm}.txt")).read())
+            tot += float(m.group(1)) * 1e6
+        traffic, src = int(tot), "profiles/r01_pmc_gemv1_{fetch,write}_size.txt (separate rocprofv3 --pmc passes)"
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "gemv1_kernel<R=2,U=4,WPB=8,SWIGLU> (gate/up GEMV + fused RMSNorm, bf16)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2), "launches_timed": launches}
+            "traffic": traffic, "traffic_source": src, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
+            "launches_timed": launches}
 
 
 def cpu_baseline(model, cfg_o, prompt_len: int, new_tokens: int, sample_tokens: int):

@@ -134,7 +134,7 @@ def test_gemm(lib, kernel, epi, M, N, K):
     res = bf16r(torch.randn(M, n_out, generator=g))
     ref = _gemm_ref(a, w, bias, epi, res)
     fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "panel": 8, "panel_ws": 8, "panel_frag": 8, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
-    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV) if kernel in ("panel_ws", "panel_frag") else None
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV) if kernel in ("panel_ws", "panel_frag") else None
     wp = _pack(w)
     wf = None
     if kernel == "panel_frag":
@@ -485,7 +485,7 @@ def test_gemm_fp8_weights(lib, M, N, K, epi):
     h = O.llama_rmsnorm(a, gamma, 1e-6) if use_norm else a
     res = bf16r(torch.randn(M, N // 2 if epi == 3 else N, generator=g))
     ref = _gemm_ref(h, wdq, None, epi, res)
-    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
     got = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, residual=res.to(DEV, torch.bfloat16), epilogue=epi, splitk_ws=ws,
                    w_q8=q, w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc,
                    norm_gamma=gamma.to(DEV) if use_norm else None, norm_eps=1e-6)

@@ -156,7 +156,7 @@ def main():
             bench_gemm("square 8192", 8192, 8192, 8192, fk=fk)
     if "skinny" in which:
         print("== skinny (k7) / panel split-K (k8) MFMA GEMM, W streamed once, rotating 4 weight buffers")
-        skws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+        skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
         for M in (2, 16, 32, 64, 128):
             for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
                 a = rnd(M, K)

@@ -91,46 +91,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
-    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS).
-    // Coalesced: LPK = D/8 adjacent lanes read one 16-byte chunk each of the SAME key row (a full row per lane group), the
-    // partial dot products are folded with LPK-wide xor shuffles; a wave covers 64/LPK keys per load instruction.
+    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS): one key per thread, 16-byte row loads.
+    // (A/B on MI355X, profiles/r01: a lane-group-per-row variant with shuffle folds was 13.3 us vs 9.2 us for this form at
+    // B = 1 and equal at B = 64, where the kernel runs at the KV-streaming rate either way.)
     const int Tk = pos + 1;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
-    constexpr int LPK = D / 8, KPW = 64 / LPK;
-    const int kc_ = lane % LPK, ksub = lane / LPK;
-    float qreg[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qreg[e] = qs[kc_ * 8 + e];
     float mx = -INFINITY;
-    constexpr int UK = 4;  // independent key groups per iteration: 4 row loads in flight before the shuffle reductions
-    for (int j0 = wave * KPW; j0 < Tk; j0 += 4 * KPW * UK) {
-        float pd[UK];
-#pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int j = j0 + u * 4 * KPW + ksub;
-            pd[u] = 0.f;
-            if (j < pos) {
-                float kv[8];
-                load8<T>(kbase + (int64_t)j * D + kc_ * 8, kv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pd[u] += qreg[e] * kv[e];
-            } else if (j == pos) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pd[u] += qreg[e] * knew[kc_ * 8 + e];
-            }
+    for (int j = tid; j < Tk; j += 256) {
+        float sv;
+        if (km && km[j] == 0) sv = -INFINITY;
+        else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
+        else {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < D; ++c) acc += qs[c] * knew[c];
+            sv = scale * acc;
         }
-#pragma unroll
-        for (int u = 0; u < UK; ++u) {
-#pragma unroll
-            for (int off = 1; off < LPK; off <<= 1) pd[u] += __shfl_xor(pd[u], off, 64);
-            const int j = j0 + u * 4 * KPW + ksub;
-            if (j < Tk) {
-                float sv = scale * pd[u];
-                if (km && km[j] == 0) sv = -INFINITY;
-                if (kc_ == 0) sc[j] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        }
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
