@@ -116,9 +116,7 @@ typedef struct vcla_gemm_args {
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */
     float norm_eps;
-    /* optional scratch for the split-K panel kernel (kernel 8): 4096 bytes of arrival counters followed by
-       >= S * M * N_pad * 4 bytes of fp32 partial tiles lets it use S K-slices.  The counter bytes must be ZERO before the
-       first use (each launch leaves them zero again); vcla_llama_* / vcla_vision_forward zero them themselves. */
+    /* optional fp32 scratch for the split-K panel kernel (kernel 8): >= S * M * N_pad * 4 bytes lets it use S K-slices */
     void* splitk_ws;
     size_t splitk_ws_bytes;
     /* optional fragment-major twin of W, [N_pad/16][K/32][64 lanes][8] bf16 (visualcla/weights.py:to_fragment_major):

@@ -490,3 +490,32 @@ def test_gemm_fp8_weights(lib, M, N, K, epi):
                    w_q8=q, w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc,
                    norm_gamma=gamma.to(DEV) if use_norm else None, norm_eps=1e-6)
     _cmp(f"gemm_fp8[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=8e-3)
+
+
+def test_panel_splitk_handoff_stress(lib):
+    """The split-K panel kernel hands fp32 partial tiles to its reduce kernel through a workspace that every GEMM of a decode
+    step reuses.  Stress: the same workspace addresses are reused back to back by launches with DIFFERENT data (a stale slab
+    read would be off by O(1)), uneven shapes, many repetitions, while a second stream keeps the memory system busy."""
+    g = torch.Generator().manual_seed(123)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    shapes = [(64, 4096, 4096), (16, 4096, 11008), (128, 12288, 4096), (33, 2048, 1408)]
+    cases = []
+    for (M, N, K) in shapes:
+        for rep in range(2):
+            a = bf16r(torch.randn(M, K, generator=g)).to(DEV, torch.bfloat16)
+            w = _pack(bf16r(torch.randn(N, K, generator=g) * 0.05))
+            ref = lib.gemm(a, w, N, out_f32=True, force_kernel=1 if M > 8 else 2)      # independent kernel, no split-K
+            cases.append((a, w, N, ref))
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for it in range(40):
+        with torch.cuda.stream(side):
+            noise.add_(1)                                   # uneven background HBM traffic
+        outs = [lib.gemm(a, w, N, out_f32=True, force_kernel=8, splitk_ws=ws) for (a, w, N, _) in cases]
+        for (a, w, N, ref), got in zip(cases, outs):
+            err = (got - ref).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (it, N, err)
+    torch.cuda.synchronize()
+    _report(f"panel split-K stress: worst |err| {worst:.3e} over 40 x {len(cases)} launches")

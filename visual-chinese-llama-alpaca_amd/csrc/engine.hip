@@ -413,7 +413,6 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
     VisionWs w;
     carve_vision(ctx, B, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     g_splitk_ws = w.splitk;
-    VCLA_CHECK_HIP(hipMemsetAsync(w.splitk, 0, 4096, s));   // split-K arrival counters
     const int M = B * N;
 
     // patch embedding: im2col -> GEMM (no bias) -> class/position embedding + pre-LN
@@ -540,7 +539,6 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     LlamaWs w;
     carve_llama(ctx, B, T, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     g_splitk_ws = w.splitk;
-    VCLA_CHECK_HIP(hipMemsetAsync(w.splitk, 0, 4096, s));   // split-K arrival counters
     VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < c.t_layers; ++l) {
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, T, pos0, nullptr, kv_cache, ctx_max, key_mask));
@@ -601,7 +599,6 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     g_splitk_ws = w.splitk;
-    VCLA_CHECK_HIP(hipMemsetAsync(w.splitk, 0, 4096, (hipStream_t)stream));
     return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
                             logits, ids_out, w);
 }
@@ -616,7 +613,6 @@ extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int 
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     g_splitk_ws = w.splitk;
-    VCLA_CHECK_HIP(hipMemsetAsync(w.splitk, 0, 4096, s));   // split-K arrival counters (every launch leaves them zero)
     // w.ids holds the current token of every sequence; each step consumes it and overwrites it with the argmax.
     VCLA_CHECK_HIP(hipMemcpyAsync(w.ids, ids_in, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
     // step_base: value of *pos_dev at the first step is unknown to the host -> the caller passes pos0 as the absolute

@@ -427,9 +427,11 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
 // register ring) -> swizzled LDS double buffer -> ds_read_b128 fragments.  Every load has the same 4-tile distance, so the
 // in-order vmcnt queue never forces an early wait.  grid = (N/128, S): S K-slices keep >= ~300 workgroups in flight; S > 1
 // writes fp32 partial tiles to a workspace and gemm_panel_reduce_kernel applies the epilogue (fixed summation order).
+// (Measured alternative, round 1: reducing inside the launch -- last-arriver ticket, agent-scope release fence per
+// workgroup -- made the kernel 20 us slower (23.9 -> 44.7 us at M=64): the per-workgroup L2 write-back costs far more
+// than the ~5 us second launch.  Kept as two launches.)
 #define PN_BN 128
 #define PN_RING 4
-#define PN_CNT_BYTES 4096   // arrival counters (one int per column tile) at the head of the split-K workspace
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
 __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -558,16 +560,9 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
 #undef PN_COMPUTE
     if (splitk == 1) {
         gemm_epilogue<EPI, OutT, MT, 2>(a, acc, 0, n0 + wave * 32, lane);
-        return;
-    }
-    // ---- split-K: publish this slice's fp32 partial tile, then the LAST workgroup to arrive for this column tile sums
-    // the S slabs in slice order (deterministic) and runs the epilogue -- no second launch.  Hand-off protocol
-    // (cdna_hip_programming.md, split-K recipe): plain slab stores -> every wave drains vmcnt -> barrier -> lane 0
-    // agent-scope RELEASE fence (+ explicit vmcnt drain the compiler cannot drop) -> relaxed agent-scope ticket;
-    // the last arriver: lane 0 agent-scope ACQUIRE fence -> barrier -> plain loads of every slab.  Placement-independent.
-    float* slab0 = partial + PN_CNT_BYTES / 4;  // counters live in the first PN_CNT_BYTES of the workspace
-    {
-        float* pp = slab0 + (int64_t)ks * a.M * n_pad;
+    } else {
+        // fp32 partial tile: partial[ks][m][n], 4 consecutive columns per lane (16-byte stores)
+        float* pp = partial + (int64_t)ks * a.M * n_pad;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = i * 16 + frow;
@@ -580,44 +575,56 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
             }
         }
     }
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* cnt = reinterpret_cast<int*>(partial) + blockIdx.x;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == splitk - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset: the next launch finds 0
-    }
-    __syncthreads();
+}
+
+// sum the S partial tiles in slice order, then bias / activation / SwiGLU / residual / store (4 columns per thread)
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(vcla_gemm_args a, int splitk, int n_pad, const float* __restrict__ partial) {
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
+    const int groups = (n_out + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * groups) return;
+    const int m = (int)(idx / groups), n = (int)(idx % groups) * 4;
+    float v[4];
+    if constexpr (EPI == VCLA_EPI_SWIGLU) {
+        const int np_ = (n >> 4) * 32 + (n & 15);  // packed gate column; up = +16
+        float gt[4] = {0, 0, 0, 0}, up[4] = {0, 0, 0, 0};
+        for (int s = 0; s < splitk; ++s) {
+            const float* pp = partial + ((int64_t)s * a.M + m) * n_pad + np_;
+            const float4 x = *reinterpret_cast<const float4*>(pp), y = *reinterpret_cast<const float4*>(pp + 16);
+            gt[0] += x.x; gt[1] += x.y; gt[2] += x.z; gt[3] += x.w;
+            up[0] += y.x; up[1] += y.y; up[2] += y.z; up[3] += y.w;
+        }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int r = 0; r < 4; ++r) {
+            if (a.w_scale) { gt[r] *= a.w_scale[np_ + r]; up[r] *= a.w_scale[np_ + 16 + r]; }
+            if (a.bias) { gt[r] += a.bias[np_ + r]; up[r] += a.bias[np_ + 16 + r]; }
+            v[r] = act_silu(gt[r]) * up[r];
+        }
+    } else {
+        float sacc[4] = {0, 0, 0, 0};
+        for (int s = 0; s < splitk; ++s) {
+            const float4 x = *reinterpret_cast<const float4*>(partial + ((int64_t)s * a.M + m) * n_pad + n);
+            sacc[0] += x.x; sacc[1] += x.y; sacc[2] += x.z; sacc[3] += x.w;
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int sl = 0; sl < splitk; ++sl) {
-        const float* pp = slab0 + (int64_t)sl * a.M * n_pad;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = i * 16 + frow;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wave * 32 + j * 16 + g * 4;
-                if (n < n_pad) {
-                    const float4 p = *reinterpret_cast<const float4*>(pp + (int64_t)m * n_pad + n);
-                    acc[i][j][0] += p.x; acc[i][j][1] += p.y; acc[i][j][2] += p.z; acc[i][j][3] += p.w;
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            float x = sacc[r];
+            if (a.w_scale) x *= a.w_scale[n + r];
+            if (a.bias && n + r < a.N) x += a.bias[n + r];
+            v[r] = epi_act<EPI>(x);
         }
     }
-    gemm_epilogue<EPI, OutT, MT, 2>(a, acc, 0, n0 + wave * 32, lane);
+    const int64_t crow = remap_row(a, m);
+    OutT* cp = (OutT*)a.C + crow * a.ldc + n;
+    const bf16_t* rp = a.residual ? (const bf16_t*)a.residual + (int64_t)m * a.ldr + n : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (n + r < n_out) {
+            float x = v[r];
+            if (rp) x += bf2f(rp[r]);
+            Act<OutT>::st(cp + r, x);
+        }
 }
 
 static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
@@ -626,8 +633,7 @@ static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
     if (s < 1) s = 1;
     if (s > 8) s = 8;
     if (s > nk) s = nk;
-    if (a->splitk_ws_bytes < PN_CNT_BYTES || tiles_n > PN_CNT_BYTES / 4) return 1;
-    while (s > 1 && (size_t)s * a->M * n_pad * 4 > a->splitk_ws_bytes - PN_CNT_BYTES) --s;  // small workspace -> fewer slices
+    while (s > 1 && (size_t)s * a->M * n_pad * 4 > a->splitk_ws_bytes) --s;  // no / small workspace -> fewer slices
     if (!a->splitk_ws) s = 1;
     return s;
 }
@@ -641,6 +647,12 @@ static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
     else if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, 1><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     else gemm_panel_kernel<EPI, OutT, MT, 0><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     VCLA_CHECK_LAUNCH("gemm_panel_kernel");
+    if (splitk > 1) {
+        const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
+        const int64_t work = (int64_t)a->M * ((n_out + 3) / 4);
+        gemm_panel_reduce_kernel<EPI, OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, splitk, n_pad, (const float*)a->splitk_ws);
+        VCLA_CHECK_LAUNCH("gemm_panel_reduce_kernel");
+    }
     return VCLA_OK;
 }
 
