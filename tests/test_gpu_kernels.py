@@ -519,3 +519,17 @@ def test_panel_splitk_handoff_stress(lib):
             assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (it, N, err)
     torch.cuda.synchronize()
     _report(f"panel split-K stress: worst |err| {worst:.3e} over 40 x {len(cases)} launches")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4 * 257, 1024, 1024, 0), (8 * 257, 4096, 1024, 1), (1100, 512, 256, 0), (2 * 256 + 128, 768, 128, 2)])
+def test_gemm_auto_dispatch_ragged_m(lib, M, N, K, epi):
+    """auto dispatch peels the M % 256 tail of ragged problems (ViT rows = B*257) into a second launch: results must be
+    seamless across the split, including bias / activation / in-place residual"""
+    g = torch.Generator().manual_seed(M + N)
+    a, w = bf16r(torch.randn(M, K, generator=g)), bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias, x = bf16r(torch.randn(N, generator=g) * 0.1), bf16r(torch.randn(M, N, generator=g))
+    ref = _gemm_ref(a, w, bias, epi, x)
+    xd = x.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, bias=bias.to(DEV), residual=xd, out=xd, epilogue=epi,
+             splitk_ws=torch.zeros(32 << 20, dtype=torch.uint8, device=DEV))
+    _cmp(f"gemm_auto_ragged[{M}x{N}x{K},epi{epi}]", xd, ref, atol=2e-3, rtol=8e-3)

@@ -154,6 +154,17 @@ def main():
             bench_gemm("llama down", Ml, 4096, 11008, fk=fk)
             bench_gemm("square 4096", 4096, 4096, 4096, fk=fk)
             bench_gemm("square 8192", 8192, 8192, 8192, fk=fk)
+    if "vit" in which:
+        print("== ViT GEMMs at B=64 through AUTO dispatch (256x256 whole rounds + 64-row tail) vs forced kernels")
+        Mv = 64 * 257
+        skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+        for tag, N, K, epi in (("qkv", 3072, 1024, 0), ("out", 1024, 1024, 0), ("fc1", 4096, 1024, 1), ("fc2", 1024, 4096, 0)):
+            a, w = rnd(Mv, K), packw(N, K)
+            out = torch.empty(Mv, N, dtype=torch.bfloat16, device=DEV)
+            for fk, nm in ((0, "auto"), (4, "256 "), (1, "128 ")):
+                t = timeit(lambda: _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws))
+                tf = 2.0 * Mv * N * K / t / 1e12
+                print(f"vit   {tag:4s} {nm} M={Mv} N={N:5d} K={K:5d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:.1f}% of peak)")
     if "skinny" in which:
         print("== skinny (k7) / panel split-K (k8) MFMA GEMM, W streamed once, rotating 4 weight buffers")
         skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)

@@ -6,14 +6,18 @@ import csv
 import sys
 
 path, counter = sys.argv[1], sys.argv[2]
+kernel_filter = sys.argv[3] if len(sys.argv) > 3 else "gemv1_kernel"
 vals = []
 with open(path) as f:
     for row in csv.DictReader(f):
         name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
-        if "gemv1_kernel" in name and row.get("Counter_Name", row.get("Counter Name", "")) == counter:
+        if kernel_filter in name and row.get("Counter_Name", row.get("Counter Name", "")) == counter:
             vals.append(float(row.get("Counter_Value", row.get("Counter Value", 0))))
 if not vals:
-    print(f"{counter}: no gemv1_kernel rows found in {path}")
+    print(f"{counter}: no {kernel_filter} rows found in {path}")
+    sys.exit(0)
+if counter not in ("FETCH_SIZE", "WRITE_SIZE"):
+    print(f"{counter}: kernel={kernel_filter} dispatches={len(vals)} mean={sum(vals) / len(vals):.4g} min={min(vals):.4g} max={max(vals):.4g}")
     sys.exit(0)
 mean_kib = sum(vals) / len(vals)
 corr = 2.0 if counter == "FETCH_SIZE" else 1.0

@@ -131,57 +131,45 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     for (int j = tid; j < Tk; j += 256) sc[j] = (mx > -INFINITY) ? Act<T>::rnd(sc[j] * inv) : 0.f;
     __syncthreads();
 
-    // ---- P V: key group = tid / HALF (0 .. 256/HALF - 1), dims 2*dl, 2*dl+1
-    constexpr int GROUPS = 256 / HALF;
-    const int grp = tid / HALF, dl = tid % HALF;
-    float o0 = 0.f, o1 = 0.f;
-    int j = grp;
-    for (; j + 3 * GROUPS < pos; j += 4 * GROUPS) {
-        float x0, y0, x1, y1, x2, y2, x3, y3;
-        ld2<T>(vbase + (int64_t)(j) * D + 2 * dl, x0, y0);
-        ld2<T>(vbase + (int64_t)(j + GROUPS) * D + 2 * dl, x1, y1);
-        ld2<T>(vbase + (int64_t)(j + 2 * GROUPS) * D + 2 * dl, x2, y2);
-        ld2<T>(vbase + (int64_t)(j + 3 * GROUPS) * D + 2 * dl, x3, y3);
-        const float p0 = sc[j], p1 = sc[j + GROUPS], p2 = sc[j + 2 * GROUPS], p3 = sc[j + 3 * GROUPS];
-        o0 += p0 * x0 + p1 * x1 + p2 * x2 + p3 * x3;
-        o1 += p0 * y0 + p1 * y1 + p2 * y2 + p3 * y3;
-    }
-    for (; j < pos; j += GROUPS) {
-        float x0, y0;
-        ld2<T>(vbase + (int64_t)j * D + 2 * dl, x0, y0);
-        o0 += sc[j] * x0;
-        o1 += sc[j] * y0;
-    }
-    if (grp == 0) {  // the new token's value comes from LDS
-        o0 += sc[pos] * vnew[2 * dl];
-        o1 += sc[pos] * vnew[2 * dl + 1];
-    }
-    // reduce the GROUPS partial outputs through LDS
-    float* pp = part;            // reuse: [GROUPS][D] <= [4][D] when HALF >= 64; for smaller D reduce in two hops
-    if (GROUPS <= 4) {
-        pp[grp * D + 2 * dl] = o0;
-        pp[grp * D + 2 * dl + 1] = o1;
-        __syncthreads();
-        if (tid < D) {
-            float v = 0.f;
+    // ---- P V.  LPK = D/8 adjacent lanes own the 8-dim chunks of ONE value row (16-byte loads, a full row per lane group),
+    // so a wave covers 64/LPK keys per load instruction and the workgroup 4x that; every thread just accumulates its 8 dims
+    // over its keys -- all loads of a pass are independent (one HBM latency per 8 keys in flight per thread).
+    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW;
+    const int vc_ = lane % LPK, vsub = wave * KPW + lane / LPK;   // chunk of the row, key slot within a block pass
+    float o[8];
 #pragma unroll
-            for (int g2 = 0; g2 < GROUPS; ++g2) v += pp[g2 * D + tid];
-            Act<T>::st(out + (int64_t)b * HD + h * D + tid, v);
-        }
-    } else {
-        // D < 128: several key groups share a wave -> fold groups inside the wave first (xor HALF, 2*HALF, ..)
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    constexpr int UV = 8;
+    for (int j0 = vsub; j0 < pos; j0 += KPB * UV) {
+        float vv[UV][8];
+        float pj[UV];
 #pragma unroll
-        for (int off = HALF; off < 64; off <<= 1) {
-            o0 += __shfl_xor(o0, off, 64);
-            o1 += __shfl_xor(o1, off, 64);
+        for (int u = 0; u < UV; ++u) {
+            const int j = j0 + u * KPB;
+            const bool ok = j < pos;
+            pj[u] = ok ? sc[j] : 0.f;
+            load8<T>(vbase + (int64_t)(ok ? j : 0) * D + vc_ * 8, vv[u]);   // clamped address; weight 0 when out of range
         }
-        if ((lane / HALF) == 0) {
-            pp[wave * D + 2 * dl] = o0;
-            pp[wave * D + 2 * dl + 1] = o1;
-        }
-        __syncthreads();
-        if (tid < D) Act<T>::st(out + (int64_t)b * HD + h * D + tid, pp[tid] + pp[D + tid] + pp[2 * D + tid] + pp[3 * D + tid]);
+#pragma unroll
+        for (int u = 0; u < UV; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pj[u] * vv[u][e];
     }
+    if (vsub == 0) {  // the new token's value comes from LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += sc[pos] * vnew[vc_ * 8 + e];
+    }
+    // fold the KPW key slots of the wave (lanes LPK apart), then the 4 waves through LDS
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off, 64);
+    if (lane < LPK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave * D + lane * 8 + e] = o[e];
+    }
+    __syncthreads();
+    if (tid < D) Act<T>::st(out + (int64_t)b * HD + h * D + tid, part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]);
 }
 
 template <typename T, int D>

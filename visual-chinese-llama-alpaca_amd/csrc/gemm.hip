@@ -1253,7 +1253,26 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
             const bool panel = a->W_frag || a->W_q8_frag || (a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32))));
             kernel = panel ? 8 : 7;
         }
-        else kernel = prefer_256(a) ? 4 : 1;
+        else {
+            // Ragged M (ViT: M = B*257): peel the M % 256 <= 128 tail rows into their own small launch so the 256x256 kernel
+            // runs WHOLE rounds (e.g. 65 x 4 tiles = 1.02 rounds -> 64 x 4 = exactly one round + a 64-row panel GEMM).
+            const int rem = a->M % 256;
+            if (rem > 0 && rem <= 128 && a->M > 256 && a->N >= 256 && a->c_group_rows <= 0) {
+                vcla_gemm_args head = *a, tail = *a;
+                head.M = a->M - rem;
+                if (prefer_256(&head)) {
+                    const size_t es = 2, cs = a->out_f32 ? 4 : 2;
+                    tail.M = rem;
+                    tail.A = (const char*)a->A + (size_t)head.M * a->lda * es;
+                    tail.C = (char*)a->C + (size_t)head.M * a->ldc * cs;
+                    if (a->residual) tail.residual = (const char*)a->residual + (size_t)head.M * a->ldr * es;
+                    head.force_kernel = 4;
+                    int rc = vcla_gemm(&head, dtype, stream);
+                    return rc ? rc : vcla_gemm(&tail, dtype, stream);
+                }
+            }
+            kernel = prefer_256(a) ? 4 : 1;
+        }
     }
     VCLA_REQUIRE(kernel >= 1 && kernel <= 8, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
     VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
