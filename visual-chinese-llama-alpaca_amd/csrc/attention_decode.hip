@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
             const int j = j0 + u * KPB;
             const bool ok = j < pos;
             pj[u] = ok ? sc[j] : 0.f;
-            load8<T>(vbase + (int64_t)(ok ? j : 0) * D + vc_ * 8, vv[u]);   // clamped address; weight 0 when out of range
+            if (ok) load8<T>(vbase + (int64_t)j * D + vc_ * 8, vv[u]);      // predicated: no traffic for slots past the context
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < UV; ++u)
