@@ -32,6 +32,7 @@
  *   vcla_vit_assemble       class/position embedding + pre_layrnorm hf:clip/modeling_clip.py:211-218,642
  *   vcla_attention          eager_attention_forward hf:clip/modeling_clip.py:259-277,
  *                           hf:llama/modeling_llama.py:191-214; modeling_visual_resampler.py:213-253
+ *   vcla_image_preprocess   (next row N1) CLIPImageProcessor.__call__ as invoked at models/visualcla/modeling_utils.py:150-152
  *   vcla_embed_splice       embed_tokens + image splice modeling_visualcla.py:280,292-305 / :346,358-370
  *   vcla_rope_kv_append     apply_rotary_pos_emb + cache update hf:llama/modeling_llama.py:130-160,255-259
  *   vcla_attn_decode_fused  the decode-step instance of LlamaAttention.forward hf:llama/modeling_llama.py:217-281
@@ -165,6 +166,16 @@ typedef struct vcla_attn_args {
 
 /* o = softmax(scale * q k^T + mask) v */
 int vcla_attention(const vcla_attn_args* args, int dtype, void* stream);
+
+/* Next-row N1: CLIP preprocessing of ONE uint8 HWC RGB image on the device (the reference does it on the host with
+   PIL/numpy, models/visualcla/modeling_utils.py:150-152): Pillow-exact fixed-point bicubic resize (coefficient tables
+   {first tap, tap count, 22-bit weights [n, kmax]} for the S cropped output columns / rows come from the host), centre
+   crop to S x S, v * rescale, (v - mean) / std (host float arrays), CHW store in the activation dtype.
+   tmp: H * S * 3 bytes of scratch.  mean3 / std3 are HOST pointers. */
+int vcla_image_preprocess(const uint8_t* img, int H, int W, uint8_t* tmp, int S, const int32_t* h_lo, const int32_t* h_cnt,
+                          const int32_t* h_k, int h_kmax, const int32_t* v_lo, const int32_t* v_cnt, const int32_t* v_k,
+                          int v_kmax, float rescale, const float* mean3, const float* std3, void* out, int dtype,
+                          void* stream);
 
 /* out[b, t] = table[ids[b, t]], except rows img_pos[b]+1 .. img_pos[b]+Q which take image_embeds[b, :]
    (img_pos[b] < 0: no image in that sample).  table is bf16 [V, D]. */

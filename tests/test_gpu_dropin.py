@@ -127,3 +127,24 @@ def test_bad_history_and_missing_path_errors(loaded):
     with pytest.raises(ValueError):
         visualcla.VisualCLAModel.from_merged_pretrained("/nonexistent/dir", torch_dtype=torch.float16, default_device="cuda:0",
                                                         device_map=None, load_in_8bit=False)
+
+
+def test_gpu_preprocess_gives_the_same_chat(loaded, tmp_path):
+    """next row N1: the loader's gpu_preprocess=True processor feeds the same pixels, so chat() answers identically"""
+    from transformers import GenerationConfig
+    from visualcla.preprocess import GpuClipImageProcessor
+    visualcla, model, tokenizer, image_processor, cfg, W = loaded
+    img = _image()
+    gc = GenerationConfig(max_new_tokens=6, do_sample=False, eos_token_id=None)
+    want, _ = visualcla.chat(model, img, "what is this?", history=[], generation_config=gc)
+    gpu_proc = GpuClipImageProcessor.from_hf(image_processor, device=model.device)
+    assert torch.equal(gpu_proc(img).pixel_values.cpu(), image_processor(img, return_tensors="pt").pixel_values)
+    model.image_processor = gpu_proc
+    try:
+        got, _ = visualcla.chat(model, img, "what is this?", history=[], generation_config=gc)
+        p = str(tmp_path / "img.png")
+        img.save(p)
+        got_path, _ = visualcla.chat(model, p, "what is this?", history=[], generation_config=gc)
+    finally:
+        model.image_processor = image_processor
+    assert got == want and got_path == want

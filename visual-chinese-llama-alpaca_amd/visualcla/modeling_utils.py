@@ -94,9 +94,10 @@ def attach_runtime(model: VisualCLAModel, tokenizer, image_processor):
 
 def get_model_and_tokenizer_and_processor(visualcla_model=None, text_model=None, vision_model=None, lora_model=None,
                                           torch_dtype=torch.float16, default_device=None, device_map=None,
-                                          load_in_8bit=False):
+                                          load_in_8bit=False, gpu_preprocess=False):
     """-> (model, tokenizer, image_processor).  `torch_dtype=float16` (the reference default) selects the bf16
-    MI355X path; float32 selects the fp32 parity mode."""
+    MI355X path; float32 selects the fp32 parity mode.  `gpu_preprocess=True` (not in the reference) swaps the returned
+    CLIPImageProcessor for `preprocess.GpuClipImageProcessor`: same call, same pixels, computed on the device."""
     from transformers import CLIPImageProcessor, LlamaTokenizer
     tokenizer = attach_special_tokens(LlamaTokenizer.from_pretrained(visualcla_model or lora_model))
     if visualcla_model is not None:
@@ -112,6 +113,9 @@ def get_model_and_tokenizer_and_processor(visualcla_model=None, text_model=None,
                                                            torch_dtype=torch_dtype, default_device=default_device,
                                                            device_map=device_map, load_in_8bit=load_in_8bit)
     image_processor = CLIPImageProcessor.from_pretrained(vision_model or visualcla_model)
+    if gpu_preprocess:
+        from .preprocess import GpuClipImageProcessor
+        image_processor = GpuClipImageProcessor.from_hf(image_processor, device=model.device)
     attach_runtime(model, tokenizer, image_processor)
     return model, tokenizer, image_processor
 
