@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] weight path: fp8 (e4m3) decode weights, bf16 activations")
+    ap.add_argument("--sample", action="store_true", help="decode under the reference's DEFAULT_GENERATION_CONFIG (sampling + "
+                    "penalties, on-device sampler) instead of greedy; a side measurement, not BASELINE's metric")
     ap.add_argument("--cpu-tokens", type=int, default=3, help="decode tokens in the bounded CPU sample")
     return ap.parse_args()
 
@@ -169,6 +171,8 @@ def main():
     px, ids, mask = px[lo:hi].to(dev, torch.bfloat16), ids[lo:hi].to(dev), mask[lo:hi].to(dev)
     kw = dict(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=args.new_tokens, do_sample=False,
               eos_token_id=None, use_graph=not args.no_graph)
+    if args.sample:   # models/visualcla/modeling_utils.py:36-47
+        kw.update(do_sample=True, top_p=0.9, top_k=40, temperature=0.5, repetition_penalty=1.1, no_repeat_ngram_size=15)
 
     def step():
         toks = model.generate(**kw)
@@ -223,7 +227,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.fp8 else "bf16 activations / fp32 accumulate, fp8-e4m3 decode weights", "data": "synthetic (random-init 7B weights, N(0,1) 224x224 pixels, synthetic ids)",
             "config": {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU, prompt T={args.prompt_len} with 64 image tokens, "
-                                    f"{args.new_tokens}-token greedy decode (BASELINE configs[{1 if B == 1 else 2}])"),
+                                    f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if args.sample else 'greedy'} decode "
+                                    f"(BASELINE configs[{1 if B == 1 else 2}])"),
                        "global_batch": gB, "seq_len": args.prompt_len, "new_tokens": args.new_tokens,
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"},
         }

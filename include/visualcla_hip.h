@@ -38,6 +38,8 @@
  *   vcla_attn_decode_fused  the decode-step instance of LlamaAttention.forward hf:llama/modeling_llama.py:217-281
  *                           (RoPE + DynamicCache.update + eager attention) in one launch
  *   vcla_argmax             greedy token selection hf:generation/utils.py (argmax over fp32 logits)
+ *   vcla_sample             (next row N2) the logits processors / warpers / draw of HF sample() under
+ *                           DEFAULT_GENERATION_CONFIG models/visualcla/modeling_utils.py:36-47
  *   vcla_vision_forward     modeling_visualcla.py:283-288 / :349-354 (and tgwebui embed_images,
  *                           scripts/inference/text_generation_webui/visualcla/visualcla.py:116-129)
  *   vcla_llama_prefill      LlamaForCausalLM.forward over the spliced embeds, modeling_visualcla.py:321-328
@@ -199,6 +201,39 @@ int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const 
 /* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
 int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);
 
+/* Next-row N2: HF's logits processors + warpers + one draw, on the device, for every sequence of the batch.
+   Replaces, per decode step, what `model.generate` runs under the reference's DEFAULT_GENERATION_CONFIG
+   (models/visualcla/modeling_utils.py:36-47) via hf:generation/logits_process.py, in HF's order:
+   repetition penalty -> no-repeat-ngram -> min-new-tokens -> temperature -> top-k -> top-p -> softmax -> draw.
+   The draw is the inverse CDF of the kept set (descending probability, ties by token id) at uniforms[h, b], h = number of
+   tokens generated so far, so the result is a pure function of (logits, history, uniforms).  top_k = 1 is greedy
+   decoding over the processed scores.  `logits` [B, ld] fp32 is MODIFIED IN PLACE (penalties / bans). */
+#define VCLA_SAMPLE_MAX_TOP_K 256
+#define VCLA_SAMPLE_MAX_EOS 4
+#define VCLA_SAMPLE_KEPT_LD 512
+typedef struct vcla_sample_args {
+    float repetition_penalty;   /* 1 = off; applied once per distinct generated token                         */
+    int no_repeat_ngram_size;   /* 0 = off                                                                    */
+    int min_new_tokens;         /* eos ids are banned while fewer tokens than this were generated; 0 = off    */
+    int n_eos;
+    int eos_ids[VCLA_SAMPLE_MAX_EOS];
+    float temperature;          /* 1 = off                                                                    */
+    int top_k;                  /* 1 .. VCLA_SAMPLE_MAX_TOP_K (ties at the k-th value are kept, like HF)       */
+    double top_p;               /* 1 = off; tokens whose ascending cumulative probability <= 1 - top_p are cut */
+    int min_tokens_to_keep;     /* >= 1                                                                       */
+    const float* uniforms;      /* device [*, B] in [0, 1): row h is consumed at history length h; NULL = 0   */
+    const int64_t* history;     /* device [*, B] step-major: the tokens generated so far (prompt excluded,
+                                   as in HF generate driven by inputs_embeds, modeling_visualcla.py:382-391)   */
+    /* optional taps of the kept set, descending probability (device, may be NULL) */
+    int64_t* kept_ids;          /* [B, VCLA_SAMPLE_KEPT_LD] */
+    float* kept_probs;          /* [B, VCLA_SAMPLE_KEPT_LD] */
+    int32_t* n_kept;            /* [B] */
+} vcla_sample_args;
+
+/* history length h = n_hist + (n_hist_dev ? *n_hist_dev : 0), at most 4096 */
+int vcla_sample(float* logits, int64_t ld, int B, int V, int n_hist, const int32_t* n_hist_dev,
+                const vcla_sample_args* args, int64_t* ids_out, void* stream);
+
 /* ---------------------------------------------------------------- model context */
 
 typedef struct vcla_model_cfg {
@@ -255,6 +290,15 @@ int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0
 int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
                            void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
                            size_t ws_bytes, int use_graph, void* stream);
+
+/* The same loop with vcla_sample in place of the argmax (sampling == NULL: greedy).  sampling->history must be the
+   step-major token buffer whose row n_hist0 + *pos_dev the step is about to produce -- i.e. ids_out - n_hist0 * B when
+   the caller keeps the n_hist0 earlier tokens (the one drawn from the prefill logits) in front of ids_out; the step reads
+   rows [0, n_hist0 + *pos_dev) of it and uniforms row n_hist0 + *pos_dev. */
+int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
+                                   void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
+                                   size_t ws_bytes, int use_graph, const vcla_sample_args* sampling, int n_hist0,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -551,8 +551,10 @@ def visualcla_forward(input_ids: Tensor, pixel_values: Optional[Tensor], attenti
 def visualcla_generate(input_ids: Tensor, pixel_values: Optional[Tensor], attention_mask: Tensor,
                        W: Dict[str, Tensor], cfg: OracleCfg, max_new_tokens: int,
                        eos_token_id: Optional[int] = None, dtype=torch.float32,
-                       return_logits: bool = False):
-    """VisualCLAModel.generate, greedy (do_sample=False): prefill over the spliced embeds with a
+                       return_logits: bool = False, select_fn=None):
+    """`select_fn(logits [B, V], generated [B, step]) -> next ids [B]` replaces the argmax (sampling oracle, next row N2).
+
+    VisualCLAModel.generate, greedy (do_sample=False): prefill over the spliced embeds with a
     KV cache, then one token per step = argmax of the fp32 last-position logits.  Returns the NEW
     tokens only, as HF does when called with inputs_embeds (modeling_utils.py:173-174)."""
     W = _cast_weights(W, dtype)
@@ -568,7 +570,10 @@ def visualcla_generate(input_ids: Tensor, pixel_values: Optional[Tensor], attent
     pad = eos_token_id if eos_token_id is not None else 0
     past = T
     for step in range(max_new_tokens):
-        nxt = logits.argmax(dim=-1)
+        if select_fn is not None:
+            nxt = select_fn(logits, torch.stack(out, dim=1) if out else torch.zeros(B, 0, dtype=torch.int64))
+        else:
+            nxt = logits.argmax(dim=-1)
         if eos_token_id is not None:
             nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
             done = done | (nxt == eos_token_id)

@@ -8,11 +8,12 @@ echo "== host"; nproc; free -g | head -2; rocminfo | grep -E "Marketing|gfx|Comp
 python -c "import torch;print(torch.__version__, torch.cuda.device_count(), torch.cuda.get_device_name(0))"
 rm -f gpurun_out/parity_report.txt
 echo "== kernel parity"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
-echo "== model parity"; timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
+echo "== model parity"; timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py tests/test_gpu_preprocess.py tests/test_gpu_sampling.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
 if [ "$mode" != "quick" ]; then
   echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
   echo "== bench"; timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 | tee gpurun_out/bench.log
   echo "== bench fp8 B=1"; timeout 600 python bench.py --fp8 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_fp8.log
+  echo "== bench sampled B=1"; timeout 600 python bench.py --sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_sample.log
   echo "== bench B=64"; timeout 600 python bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 | tee gpurun_out/bench_b64.log
   echo "== kernel microbench"; timeout 900 python tools/bench_kernels.py vit 2>&1 | grep -v amdgpu.ids | tee gpurun_out/kernels.log
   echo "== rocprof B=64"; rm -rf gpurun_out/prof64; (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof64 -o bench -- python $GRAFT_REPO_ROOT/bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -1); f=$(find gpurun_out/prof64 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-200; find gpurun_out/prof64 -name "*kernel_trace.csv" -delete

@@ -9,6 +9,7 @@
 // Memory: nothing is allocated here.  Weights are caller-owned device tensors registered by name; activations
 // live in a caller-provided workspace carved by a bump allocator; the KV cache is caller-owned.
 #include "vcla_common.h"
+#include <string.h>
 
 #include <new>
 #include <string>
@@ -114,6 +115,8 @@ struct vcla_ctx {
         const void *ids, *kv, *mask, *ws, *out;
         int B, pos0, ctx_max, step_base;
         const void* pos_dev;
+        int has_samp, n_hist0;
+        vcla_sample_args samp;
     } graph_key = {};
 };
 
@@ -559,7 +562,7 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
 
 static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
                             int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
-                            int64_t* ids_out, const LlamaWs& w) {
+                            int64_t* ids_out, const LlamaWs& w, const vcla_sample_args* samp = nullptr, int n_hist0 = 0) {
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
@@ -573,7 +576,8 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
         RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
     }
-    if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
+    if (ids_out && samp) RUN(vcla_sample_launch(lg, c.t_vocab, B, c.t_vocab, n_hist0, pos_dev, samp, ids_out, s));
+    else if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
     if (advance_pos && pos_dev) {
         advance_pos_kernel<<<1, 1, 0, s>>>(pos_dev);
         VCLA_CHECK_LAUNCH("advance_pos_kernel");
@@ -606,8 +610,17 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
 extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
                                       void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
                                       size_t ws_bytes, int use_graph, void* stream) {
+    return vcla_llama_decode_loop_sampled(ctx, ids_in, B, pos0, pos_dev, n_steps, kv_cache, ctx_max, key_mask, ids_out, ws, ws_bytes,
+                                          use_graph, nullptr, 0, stream);
+}
+
+extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev, int n_steps,
+                                              void* kv_cache, int ctx_max, const int32_t* key_mask, int64_t* ids_out, void* ws,
+                                              size_t ws_bytes, int use_graph, const vcla_sample_args* sampling, int n_hist0,
+                                              void* stream) {
     RUN(check_decode_args(ctx, ids_in, B, pos0, pos_dev, kv_cache, ctx_max, ws, ws_bytes));
     VCLA_REQUIRE(pos_dev && ids_out && n_steps >= 0, VCLA_ERR_BAD_ARG, "llama_decode_loop: needs pos_dev, ids_out, n_steps >= 0");
+    VCLA_REQUIRE(!sampling || (sampling->history && n_hist0 >= 0), VCLA_ERR_BAD_ARG, "llama_decode_loop: sampling needs the history buffer");
     if (n_steps == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
     LlamaWs w;
@@ -619,7 +632,7 @@ extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int 
     // position of the first decoded token and keeps *pos_dev == 0 at entry (documented in INTEGRATION.md).
     const int step_base = 0;
     auto one_step = [&](hipStream_t st) -> int {
-        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w));
+        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0));
         record_ids_kernel<<<(B + 63) / 64, 64, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B);
         VCLA_CHECK_LAUNCH("record_ids_kernel");
         advance_pos_kernel<<<1, 1, 0, st>>>(pos_dev);
@@ -634,7 +647,8 @@ extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int 
     auto& k = ctx->graph_key;
     const bool same = ctx->graph_exec && k.ids == (const void*)w.ids && k.kv == kv_cache && k.mask == (const void*)key_mask &&
                       k.ws == ws && k.out == (const void*)ids_out && k.B == B && k.pos0 == pos0 && k.ctx_max == ctx_max &&
-                      k.pos_dev == (const void*)pos_dev && k.step_base == step_base;
+                      k.pos_dev == (const void*)pos_dev && k.step_base == step_base && k.has_samp == (sampling != nullptr) &&
+                      (!sampling || (k.n_hist0 == n_hist0 && memcmp(&k.samp, sampling, sizeof(*sampling)) == 0));
     if (!same) {
         if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
@@ -648,6 +662,8 @@ extern "C" int vcla_llama_decode_loop(vcla_ctx* ctx, const int64_t* ids_in, int 
         if (ie != hipSuccess) { ctx->graph_exec = nullptr; return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
         k.ids = w.ids; k.kv = kv_cache; k.mask = key_mask; k.ws = ws; k.out = ids_out; k.B = B; k.pos0 = pos0;
         k.ctx_max = ctx_max; k.pos_dev = pos_dev; k.step_base = step_base;
+        k.has_samp = sampling != nullptr; k.n_hist0 = n_hist0;
+        if (sampling) memcpy(&k.samp, sampling, sizeof(*sampling));
     }
     for (int i = 0; i < n_steps; ++i) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, s));
     return VCLA_OK;

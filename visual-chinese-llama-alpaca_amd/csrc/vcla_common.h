@@ -39,6 +39,10 @@ int vcla_fail(int code, const char* fmt, ...);
         if (!(cond)) return vcla_fail(code, __VA_ARGS__);                                     \
     } while (0)
 
+// sample.hip: the launch behind vcla_sample, shared with the decode loop
+int vcla_sample_launch(float* logits, int64_t ld, int B, int V, int n_hist, const int32_t* n_hist_dev, const vcla_sample_args* a,
+                       int64_t* out, hipStream_t s);
+
 static inline size_t vcla_dtype_size(int dtype) { return dtype == VCLA_F32 ? 4 : 2; }
 static inline bool vcla_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 

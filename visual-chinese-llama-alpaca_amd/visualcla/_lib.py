@@ -70,6 +70,33 @@ class ModelCfg(C.Structure):
     ]
 
 
+SAMPLE_MAX_TOP_K, SAMPLE_MAX_EOS, SAMPLE_KEPT_LD, SAMPLE_MAX_HIST = 256, 4, 512, 4096
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [
+        ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int), ("min_new_tokens", C.c_int),
+        ("n_eos", C.c_int), ("eos_ids", C.c_int * SAMPLE_MAX_EOS),
+        ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_double), ("min_tokens_to_keep", C.c_int),
+        ("uniforms", C.c_void_p), ("history", C.c_void_p),
+        ("kept_ids", C.c_void_p), ("kept_probs", C.c_void_p), ("n_kept", C.c_void_p),
+    ]
+
+
+def sample_args(repetition_penalty=1.0, no_repeat_ngram_size=0, min_new_tokens=0, eos_ids=(), temperature=1.0, top_k=1,
+                top_p=1.0, min_tokens_to_keep=1, uniforms=None, history=None, kept_ids=None, kept_probs=None, n_kept=None):
+    a = SampleArgs()
+    a.repetition_penalty, a.no_repeat_ngram_size, a.min_new_tokens = float(repetition_penalty), int(no_repeat_ngram_size), int(min_new_tokens)
+    eos_ids = list(eos_ids)[:SAMPLE_MAX_EOS]
+    a.n_eos = len(eos_ids)
+    for i, e in enumerate(eos_ids):
+        a.eos_ids[i] = int(e)
+    a.temperature, a.top_k, a.top_p, a.min_tokens_to_keep = float(temperature), int(top_k), float(top_p), int(min_tokens_to_keep)
+    a.uniforms, a.history = ptr(uniforms), ptr(history)
+    a.kept_ids, a.kept_probs, a.n_kept = ptr(kept_ids), ptr(kept_probs), ptr(n_kept)
+    return a
+
+
 # every symbol include/visualcla_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -89,6 +116,7 @@ SYMBOLS = {
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _vp]),
     "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
+    "vcla_sample": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(SampleArgs), _vp, _vp]),
     "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "vcla_ctx_destroy": (None, [_vp]),
     "vcla_ctx_set_tensor": (_i, [_vp, C.c_char_p, _vp, _sz]),
@@ -100,6 +128,7 @@ SYMBOLS = {
     "vcla_llama_prefill": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "vcla_llama_decode_step": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vcla_llama_decode_loop": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+    "vcla_llama_decode_loop_sampled": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _i, C.POINTER(SampleArgs), _i, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -223,6 +252,15 @@ def attention(q, k, v, scale, causal=False, key_mask=None, out=None, force_kerne
     a.key_mask, a.key_mask_ld = ptr(key_mask), (key_mask.stride(0) if key_mask is not None else 0)
     a.tk_dev, a.tk_dev_add, a.force_kernel = None, 0, force_kernel
     check(lib.vcla_attention(C.byref(a), dtype_code(q.dtype), stream_ptr()))
+    return out
+
+
+def sample(logits, args: SampleArgs, n_hist: int = 0):
+    """logits [B, V] fp32 (modified in place) -> next tokens [B] int64; args.history / args.uniforms as the header documents"""
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    check(load().vcla_sample(logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1], int(n_hist), None, C.byref(args),
+                             out.data_ptr(), stream_ptr()))
     return out
 
 

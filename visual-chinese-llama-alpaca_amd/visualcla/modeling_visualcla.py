@@ -559,13 +559,34 @@ class VisualCLAModel:
                 procs.append(LP.TopPLogitsWarper(top_p=gc.top_p))
         return procs
 
+    def _device_sampling(self, gc, n_new: int):
+        """kwargs for _lib.sample_args when the generation config maps onto the on-device sampler (next row N2), else None"""
+        eos = self._eos_list(gc)
+        mnt = int(getattr(gc, "min_new_tokens", None) or 0) if eos else 0
+        if len(eos) > _lib.SAMPLE_MAX_EOS and mnt:
+            return None
+        if n_new > _lib.SAMPLE_MAX_HIST:
+            return None
+        kw = dict(repetition_penalty=gc.repetition_penalty if gc.repetition_penalty is not None else 1.0,
+                  no_repeat_ngram_size=gc.no_repeat_ngram_size or 0, min_new_tokens=mnt, eos_ids=eos if mnt else ())
+        if gc.do_sample:
+            k = gc.top_k if gc.top_k is not None else 0
+            if not 1 <= k <= _lib.SAMPLE_MAX_TOP_K:
+                return None                                   # top_k off / huge: full-vocabulary sort, host path
+            kw.update(temperature=gc.temperature if gc.temperature is not None else 1.0, top_k=k,
+                      top_p=gc.top_p if gc.top_p is not None else 1.0)
+        return kw
+
     @torch.no_grad()
     def generate(self, input_ids=None, pixel_values=None, attention_mask=None, generation_config=None,
                  logits_processor=None, stopping_criteria=None, prefix_allowed_tokens_fn=None, synced_gpus=False,
-                 use_graph: Optional[bool] = None, **kwargs):
+                 use_graph: Optional[bool] = None, device_sampling: Optional[bool] = None, **kwargs):
         """Same contract as the reference generate (modeling_visualcla.py:334-392): returns the NEW tokens only,
         LongTensor [B, n_new] (what HF generate returns when driven by inputs_embeds).  Greedy decoding without
-        callbacks runs entirely on the device (argmax feeds the next step; optional hipGraph replay)."""
+        callbacks runs entirely on the device (argmax feeds the next step; optional hipGraph replay); so does sampling /
+        greedy with HF's standard processors (repetition penalty, no-repeat-ngram, min-new-tokens, temperature, top-k <= 256,
+        top-p) through vcla_sample, drawing from torch.rand(n_new, B) of the device generator.  Custom logits processors,
+        stopping criteria (streaming) or top_k = 0 take the host-driven path (HF processors + torch.multinomial)."""
         lib = _lib.load()
         if prefix_allowed_tokens_fn is not None:
             raise ValueError("prefix_allowed_tokens_fn is not supported")
@@ -600,11 +621,25 @@ class VisualCLAModel:
         if use_graph is None:
             use_graph = os.environ.get("VCLA_DECODE_GRAPH", "1") != "0"
 
-        fast = not procs and not criteria and not gc.do_sample
+        plain_greedy = not procs and not gc.do_sample
+        samp_kw = None
+        if not plain_greedy and not logits_processor and not criteria and device_sampling is not False:
+            samp_kw = self._device_sampling(gc, n_new)
+        if device_sampling and samp_kw is None and not plain_greedy:
+            raise ValueError("device_sampling=True but the generation config needs the host path (custom processors, "
+                             "stopping criteria, or top_k outside [1, %d])" % _lib.SAMPLE_MAX_TOP_K)
+        fast = not criteria and (plain_greedy or samp_kw is not None)
         if fast:
-            # ---- device-resident greedy loop
-            first = _lib.argmax(logits)
+            # ---- device-resident loop: argmax, or the on-device sampler, feeds the next step
             out = torch.empty(n_new, B, dtype=torch.int64, device=self._device)
+            samp = None
+            if samp_kw is not None:
+                self._uniforms = torch.rand(n_new, B, device=self._device) if gc.do_sample else None
+                samp = _lib.sample_args(uniforms=self._uniforms, history=out, **samp_kw)
+                with torch.cuda.device(self._device):
+                    first = _lib.sample(logits, samp, n_hist=0)
+            else:
+                first = _lib.argmax(logits)
             out[0] = first
             done_at = n_new
             step, chunk = 1, (n_new if not eos else 32)
@@ -623,10 +658,10 @@ class VisualCLAModel:
                 # the captured graph (keyed on buffers + pos0) is reused for the whole generate() call
                 while step < n_new:
                     k = min(chunk, n_new - step)
-                    _lib.check(lib.vcla_llama_decode_loop(self._ctx, out[step - 1].data_ptr(), B, T, self._pos_dev.data_ptr(), k,
-                                                          cache.kv.data_ptr(), ctx_max, _lib.ptr(key_mask),
-                                                          out[1:].data_ptr(), ws.data_ptr(), ws.numel(), int(use_graph),
-                                                          _lib.stream_ptr()))
+                    _lib.check(lib.vcla_llama_decode_loop_sampled(
+                        self._ctx, out[step - 1].data_ptr(), B, T, self._pos_dev.data_ptr(), k, cache.kv.data_ptr(), ctx_max,
+                        _lib.ptr(key_mask), out[1:].data_ptr(), ws.data_ptr(), ws.numel(), int(use_graph),
+                        C.byref(samp) if samp is not None else None, 1, _lib.stream_ptr()))
                     step += k
                     if eos_t is not None and bool(torch.isin(out[:step], eos_t).any(dim=0).all()):
                         done_at = step
