@@ -210,6 +210,7 @@ int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V,
    decoding over the processed scores.  `logits` [B, ld] fp32 is MODIFIED IN PLACE (penalties / bans). */
 #define VCLA_SAMPLE_MAX_TOP_K 256
 #define VCLA_SAMPLE_MAX_EOS 4
+#define VCLA_SAMPLE_MAX_VOCAB 53248 /* the logits row is held in the registers of one 1024-thread workgroup */
 #define VCLA_SAMPLE_KEPT_LD 512
 typedef struct vcla_sample_args {
     float repetition_penalty;   /* 1 = off; applied once per distinct generated token                         */

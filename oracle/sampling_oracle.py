@@ -15,6 +15,10 @@ The history the processors see is the GENERATED tokens only: the reference drive
 and the HIP kernel draw by inverse CDF over the kept set in descending probability (ties: lower token id first) at a given
 uniform, which has the same distribution and is a pure function of its inputs.
 
+Ties: HF's top-p cut removes a prefix of `torch.sort(scores)`, and torch.sort is not stable, so WHICH of several equal
+scores straddling the cut survive is implementation-defined in the reference stack; this oracle (and the kernel) use the
+stable order -- lower token ids are dropped first.  The draw order breaks ties by ascending id (top_k = 1 == torch.argmax).
+
 TEST INFRASTRUCTURE ONLY.  Pinned in tests/test_sampling_oracle.py against the HF classes themselves (transformers is
 installed here and on the GPU box).
 """

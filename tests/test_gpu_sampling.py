@@ -177,3 +177,10 @@ def test_sampling_is_reproducible_and_seed_dependent_in_bf16():
         torch.manual_seed(seed)
         outs.append(model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=gc).cpu())
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+def test_top_p_cut_inside_a_tie_group_matches_the_oracle_convention():
+    logits = np.full((1, 64), -30.0, np.float32)
+    logits[0, [5, 9, 20, 33, 40, 41]] = [3.0, 1.0, 1.0, 1.0, 1.0, 2.0]
+    for top_p in (0.75, 0.8, 0.85, 0.9, 0.95):
+        _check(logits, np.zeros((0, 1), np.int64), S.SampleCfg(top_k=50, top_p=top_p), np.array([0.97], np.float32))

@@ -166,3 +166,64 @@ def test_data_parallel_gather_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_python_constants_match_the_header():
+    from visualcla import _lib
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "visualcla_hip.h")).read()
+    for name, val in (("VCLA_SAMPLE_MAX_TOP_K", _lib.SAMPLE_MAX_TOP_K), ("VCLA_SAMPLE_MAX_EOS", _lib.SAMPLE_MAX_EOS),
+                      ("VCLA_SAMPLE_KEPT_LD", _lib.SAMPLE_KEPT_LD), ("VCLA_SAMPLE_MAX_VOCAB", _lib.SAMPLE_MAX_VOCAB)):
+        m = re.search(rf"#define {name} (\d+)", hdr)
+        assert m and int(m.group(1)) == val, name
+
+
+def test_fold_lora_formula_modules_to_save_and_errors():
+    from visualcla.weights import fold_lora
+    g = torch.Generator().manual_seed(0)
+    base = {"text_model.model.layers.0.self_attn.q_proj.weight": torch.randn(8, 8, generator=g),
+            "text_model.model.layers.0.self_attn.v_proj.weight": torch.randn(8, 8, generator=g).half(),
+            "text_model.model.embed_tokens.weight": torch.randn(10, 8, generator=g),
+            "vision_model.encoder.layers.0.self_attn.q_proj.weight": torch.randn(8, 8, generator=g),      # flat (transformers 5.x)
+            "image_projection_layer.weight": torch.zeros(8, 8)}
+    want = {k: v.clone().float() for k, v in base.items()}
+    r, alpha = 2, 8
+    A = {k: torch.randn(r, 8, generator=g) for k in "qvc"}
+    Bm = {k: torch.randn(8, r, generator=g) for k in "qvc"}
+    new_embed, new_proj = torch.randn(14, 8, generator=g), torch.randn(8, 8, generator=g)
+    adapter = {
+        "base_model.model.text_model.model.layers.0.self_attn.q_proj.lora_A.weight": A["q"],
+        "base_model.model.text_model.model.layers.0.self_attn.q_proj.lora_B.weight": Bm["q"],
+        "base_model.model.text_model.model.layers.0.self_attn.v_proj.lora_A.default.weight": A["v"],       # newer peft naming
+        "base_model.model.text_model.model.layers.0.self_attn.v_proj.lora_B.default.weight": Bm["v"],
+        "base_model.model.vision_model.vision_model.encoder.layers.0.self_attn.q_proj.lora_A.weight": A["c"],   # 4.x nesting
+        "base_model.model.vision_model.vision_model.encoder.layers.0.self_attn.q_proj.lora_B.weight": Bm["c"],
+        "base_model.model.text_model.model.embed_tokens.weight": new_embed,                                  # modules_to_save
+        "base_model.model.image_projection_layer.modules_to_save.default.weight": new_proj,
+    }
+    out = fold_lora(base, adapter, {"r": r, "lora_alpha": alpha})
+    s = alpha / r
+    torch.testing.assert_close(out["text_model.model.layers.0.self_attn.q_proj.weight"], want["text_model.model.layers.0.self_attn.q_proj.weight"] + s * Bm["q"] @ A["q"])
+    torch.testing.assert_close(out["text_model.model.layers.0.self_attn.v_proj.weight"], want["text_model.model.layers.0.self_attn.v_proj.weight"] + s * Bm["v"] @ A["v"])
+    torch.testing.assert_close(out["vision_model.encoder.layers.0.self_attn.q_proj.weight"], want["vision_model.encoder.layers.0.self_attn.q_proj.weight"] + s * Bm["c"] @ A["c"])
+    assert torch.equal(out["text_model.model.embed_tokens.weight"], new_embed) and torch.equal(out["image_projection_layer.weight"], new_proj)
+    # fan_in_fan_out stores the delta transposed
+    b2 = {"w.weight": torch.zeros(8, 8)}
+    fold_lora(b2, {"w.lora_A.weight": A["q"], "w.lora_B.weight": Bm["q"]}, {"r": r, "lora_alpha": alpha, "fan_in_fan_out": True})
+    torch.testing.assert_close(b2["w.weight"], (s * Bm["q"] @ A["q"]).t())
+    with pytest.raises(KeyError):
+        fold_lora({"w.weight": torch.zeros(8, 8)}, {"nope.lora_A.weight": A["q"], "nope.lora_B.weight": Bm["q"]}, {"r": r, "lora_alpha": alpha})
+    with pytest.raises(KeyError):
+        fold_lora({"w.weight": torch.zeros(8, 8)}, {"w.lora_A.weight": A["q"]}, {"r": r, "lora_alpha": alpha})
+    with pytest.raises(ValueError):
+        fold_lora({"w.weight": torch.zeros(8, 8)}, {"w.lora_A.weight": A["q"], "w.lora_B.weight": Bm["q"]}, {"r": 4, "lora_alpha": alpha})
+
+
+def test_tgwebui_pipeline_statics_and_missing_settings():
+    from visualcla import tgwebui as T
+    P = T.VisualCLA_7B_Pipeline
+    assert (P.name(), P.placeholder_token_id(), P.visualcla_projector_shape(), P.num_image_embeds()) == ("visualcla-7b", 49957, (1024, 4096), 64)
+    assert (P.image_start(), P.image_end(), P.image_placeholder()) == ("<img>", "</img>", "<img_token>")
+    assert T.available_pipelines == ["visualcla-7b"] and T.get_pipeline("llava-7b", {}) is None
+    assert T.get_pipeline_from_model_name("llama-13b", {}) is None
+    with pytest.raises(KeyError):
+        T.get_pipeline("visualcla-7b", {})

@@ -91,3 +91,19 @@ def test_sample_step_batch_layout():
     got = S.sample_step(logits, hist, cfg, u)
     for b in range(B):
         assert got[b] == S.draw(S.process_scores(logits[b], hist[:, b], cfg), float(u[b]))[0]
+
+
+def test_top_p_cut_inside_a_tie_group():
+    """equal scores straddling the top-p boundary: HF removes a prefix of torch.sort's ascending order, whose order inside a
+    tie is implementation-defined (torch.sort is not stable).  What is defined -- how MANY survive and their scores -- must
+    match HF; the oracle (and the kernel) fix the free choice as a stable sort would: lower token ids are dropped first."""
+    logits = np.full(64, -30.0, np.float32)
+    logits[[5, 9, 20, 33, 40, 41]] = [3.0, 1.0, 1.0, 1.0, 1.0, 2.0]
+    kept = {}
+    for top_p in (0.75, 0.8, 0.85, 0.9, 0.95):
+        cfg = S.SampleCfg(top_k=50, top_p=top_p)
+        got = S.process_scores(logits, [], cfg)
+        want = hf_scores(logits, [], cfg)
+        assert np.array_equal(np.sort(got), np.sort(want)), top_p
+        kept[top_p] = np.nonzero(~np.isinf(got))[0].tolist()
+    assert kept[0.75] == [5, 40, 41] and kept[0.8] == [5, 33, 40, 41] and kept[0.9] == [5, 20, 33, 40, 41]

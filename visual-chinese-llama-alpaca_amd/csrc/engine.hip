@@ -142,8 +142,11 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
     VCLA_REQUIRE(c.r_hidden == c.v_hidden, VCLA_ERR_BAD_SHAPE,
                  "ctx_create: resampler hidden (%d) must equal vision hidden (%d): latents are concatenated with image tokens",
                  c.r_hidden, c.v_hidden);
-    VCLA_REQUIRE(c.v_patch > 0 && c.v_image % c.v_patch == 0 && c.v_layers > 0 && c.r_layers > 0 && c.t_layers > 0 &&
-                     c.r_queries > 0 && c.t_vocab > 0 && c.t_max_pos > 0 && c.v_channels > 0,
+    // t_layers == 0 && t_vocab == 0: a vision-only context (ViT + resampler + projection into t_hidden), the half the
+    // text-generation-webui pipeline consumes (next row N4); the llama entry points refuse it.
+    const bool vision_only = c.t_layers == 0 && c.t_vocab == 0;
+    VCLA_REQUIRE(c.v_patch > 0 && c.v_image % c.v_patch == 0 && c.v_layers > 0 && c.r_layers > 0 && c.r_queries > 0 && c.v_channels > 0 &&
+                     (vision_only || (c.t_layers > 0 && c.t_vocab > 0 && c.t_max_pos > 0)),
                  VCLA_ERR_BAD_SHAPE, "ctx_create: bad geometry");
     vcla_ctx* x = new (std::nothrow) vcla_ctx();
     VCLA_REQUIRE(x, VCLA_ERR_BAD_ARG, "ctx_create: out of host memory");
@@ -257,6 +260,10 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
     }
     GET_W(ctx->proj_w, "proj.w", c.t_hidden, c.r_hidden);
     GET_F(ctx->proj_b, "proj.b", c.t_hidden);
+    if (c.t_layers == 0) {   // vision-only context
+        ctx->finalized = true;
+        return VCLA_OK;
+    }
     {
         const void* e;
         int rc = get_tensor(ctx, "llama.embed", (size_t)c.t_vocab * c.t_hidden * 2, &e);
@@ -528,7 +535,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
 extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache,
                                   int ctx_max, const int32_t* key_mask, float* logits, int all_logits, void* ws,
                                   size_t ws_bytes, void* layer_tap, void* stream) {
-    VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "llama_prefill: context not finalized");
+    VCLA_REQUIRE(ctx && ctx->finalized && ctx->c.t_layers > 0, VCLA_ERR_BAD_ARG, "llama_prefill: context not finalized, or vision-only");
     VCLA_REQUIRE(inputs_embeds && kv_cache && ws, VCLA_ERR_BAD_ARG, "llama_prefill: null pointer");
     const vcla_model_cfg& c = ctx->c;
     VCLA_REQUIRE(B > 0 && T > 0 && pos0 >= 0 && pos0 + T <= ctx_max && ctx_max <= c.t_max_pos, VCLA_ERR_BAD_SHAPE,
@@ -587,7 +594,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
 
 static int check_decode_args(vcla_ctx* ctx, const int64_t* ids_in, int B, int pos0, const int32_t* pos_dev, void* kv_cache,
                              int ctx_max, void* ws, size_t ws_bytes) {
-    VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "llama_decode: context not finalized");
+    VCLA_REQUIRE(ctx && ctx->finalized && ctx->c.t_layers > 0, VCLA_ERR_BAD_ARG, "llama_decode: context not finalized, or vision-only");
     VCLA_REQUIRE(ids_in && kv_cache && ws, VCLA_ERR_BAD_ARG, "llama_decode: null pointer");
     VCLA_REQUIRE(B > 0 && pos0 >= 0 && ctx_max <= ctx->c.t_max_pos && (pos_dev || pos0 < ctx_max), VCLA_ERR_BAD_SHAPE,
                  "llama_decode: B=%d pos0=%d ctx_max=%d (max_pos %d)", B, pos0, ctx_max, ctx->c.t_max_pos);

@@ -40,7 +40,13 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
         acc >>= 22;
         acc = acc < 0 ? 0 : (acc > 255 ? 255 : acc);
         const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        const float v = __fdiv_rn(__fsub_rn(__fmul_rn((float)acc, rescale), mean), sd);   // same op order as numpy, no FMA
+        float v;
+        {
+#pragma clang fp contract(off)   // numpy rounds after the multiply and after the subtract: an FMA here is 1 ulp off
+            const float scaled = (float)acc * rescale;
+            const float centred = scaled - mean;
+            v = centred / sd;   // hipcc's default fp32 divide is correctly rounded
+        }
         Act<T>::st(out + ((int64_t)c * S + y) * S + x, v);
     }
 }

@@ -12,6 +12,7 @@
 #define SAMPLE_THREADS 1024
 #define SAMPLE_CAP 512       // kept-set capacity: top_k <= 256 plus ties at the k-th value
 #define SAMPLE_MAX_HIST 4096 // generated tokens visible to the repetition / n-gram processors (max_position_embeddings = 2048)
+#define SAMPLE_PER_THREAD 52 // logits per thread held in registers (no spills at 128 VGPRs): V <= 53248
 #define SAMPLE_BIN_COPIES 8  // histogram replicas: spreads same-bin LDS atomics of neighbouring lanes
 
 // order-preserving float -> unsigned key (ascending)
@@ -38,6 +39,8 @@ struct SampleParams {
     int32_t* n_kept;
 };
 
+static_assert(SAMPLE_THREADS * SAMPLE_PER_THREAD == VCLA_SAMPLE_MAX_VOCAB, "register slice must cover the largest vocabulary");
+
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restrict__ logits, int64_t ld, int V, int B, int n_hist,
                                                                 const int32_t* __restrict__ n_hist_dev, SampleParams a,
                                                                 int64_t* __restrict__ out) {
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
             for (int j = 0; j < i && first; ++j) first = s_hist[j] != tok;
             if (first) {
                 const float v = x[tok];
-                x[tok] = v < 0.f ? v * a.repetition_penalty : __fdiv_rn(v, a.repetition_penalty);
+                x[tok] = v < 0.f ? v * a.repetition_penalty : v / a.repetition_penalty;
             }
         }
         __syncthreads();
@@ -82,17 +85,27 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
     if (tid < a.n_eos && h < a.min_new_tokens && a.eos[tid] >= 0 && a.eos[tid] < V) x[a.eos[tid]] = -INFINITY;
     __syncthreads();
 
-    // ---- TopKLogitsWarper: exact k-th largest key by 4 x 8-bit radix select (TemperatureLogitsWarper applied on read)
+    // ---- TemperatureLogitsWarper on read: this thread's slice of the row goes to registers once (64 loads in flight),
+    //      the radix passes below never touch memory again
     const float T = a.temperature;
+    float y[SAMPLE_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
+        const int i = tid + j * SAMPLE_THREADS;
+        y[j] = i < V ? x[i] / T : -INFINITY;
+    }
+    // ---- TopKLogitsWarper: exact k-th largest key by 4 x 8-bit radix select
     if (tid == 0) { s_prefix = 0u; s_kk = a.top_k < V ? a.top_k : V; s_ncand = 0; }
     unsigned mask = 0u;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256 * SAMPLE_BIN_COPIES; i += SAMPLE_THREADS) s_bins[i] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
-        for (int i = tid; i < V; i += SAMPLE_THREADS) {
-            const unsigned key = fkey(__fdiv_rn(x[i], T));
-            if ((key & mask) == prefix) atomicAdd(&s_bins[((key >> shift) & 255u) * SAMPLE_BIN_COPIES + (tid & (SAMPLE_BIN_COPIES - 1))], 1u);
+#pragma unroll
+        for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
+            const unsigned key = fkey(y[j]);
+            if (tid + j * SAMPLE_THREADS < V && (key & mask) == prefix)
+                atomicAdd(&s_bins[((key >> shift) & 255u) * SAMPLE_BIN_COPIES + (tid & (SAMPLE_BIN_COPIES - 1))], 1u);
         }
         __syncthreads();
         if (tid < 256) {
@@ -117,21 +130,22 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
     }
     // ---- kept candidates: everything >= the k-th value (HF removes `scores < kth`, so ties stay), -inf never
     const unsigned thr = s_prefix;
-    for (int i = tid; i < V; i += SAMPLE_THREADS) {
-        const float y = __fdiv_rn(x[i], T);
-        if (fkey(y) >= thr && y > -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
+        if (fkey(y[j]) >= thr && y[j] > -INFINITY) {   // slots past V hold -inf
             const int slot = atomicAdd(&s_ncand, 1);
-            if (slot < SAMPLE_CAP) { s_cv[slot] = y; s_ci[slot] = i; }
+            if (slot < SAMPLE_CAP) { s_cv[slot] = y[j]; s_ci[slot] = tid + j * SAMPLE_THREADS; }
         }
     }
     __syncthreads();
     const int nc = s_ncand < SAMPLE_CAP ? s_ncand : SAMPLE_CAP;
-    // rank sort: descending value, ascending index
+    // rank sort, descending value; ties in DESCENDING index = the reverse of the stable ascending sort HF's top-p cut walks
+    // (torch.sort on the scores), so a cut that falls inside a group of equal scores drops the lower token ids first
     for (int t = tid; t < nc; t += SAMPLE_THREADS) {
         const float v = s_cv[t];
         const int idx = s_ci[t];
         int rank = 0;
-        for (int j = 0; j < nc; ++j) rank += (s_cv[j] > v) || (s_cv[j] == v && s_ci[j] < idx);
+        for (int j = 0; j < nc; ++j) rank += (s_cv[j] > v) || (s_cv[j] == v && s_ci[j] > idx);
         s_sv[rank] = v;
         s_si[rank] = idx;
     }
@@ -152,12 +166,27 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
             float c = 0.f;
             keep = 0;
             for (int r = nc - 1; r >= 0; --r) {
-                c += __fdiv_rn(s_cv[r], Z);
+                c += s_cv[r] / Z;
                 if (c > a.top_p_complement) { keep = r + 1; break; }
             }
             if (keep < a.min_keep) keep = a.min_keep < nc ? a.min_keep : nc;
         }
-        // ---- softmax over the survivors + inverse-CDF draw
+        s_kk = keep;
+    }
+    __syncthreads();
+    const int keep = s_kk;
+    // ---- the draw walks the survivors in descending probability with ties in ASCENDING token id (so top_k = 1 is
+    //      torch.argmax: first maximum): re-rank inside the kept prefix
+    for (int t = tid; t < keep; t += SAMPLE_THREADS) {
+        const float v = s_sv[t];
+        const int idx = s_si[t];
+        int rank = 0;
+        for (int j = 0; j < keep; ++j) rank += (s_sv[j] > v) || (s_sv[j] == v && s_si[j] < idx);
+        s_ci[rank] = idx;
+    }
+    __syncthreads();
+    // s_cv (exp of the value) is constant inside a tie group, so it is already in the final order
+    if (tid == 0) {
         float Zk = 0.f;
         for (int r = 0; r < keep; ++r) Zk += s_cv[r];
         const float u = a.uniforms ? a.uniforms[(int64_t)h * B + b] : 0.f;
@@ -168,18 +197,16 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
             c += s_cv[r];
             if (c > target) { pick = r; break; }
         }
-        out[b] = s_si[pick];
+        out[b] = s_ci[pick];
         if (a.n_kept) a.n_kept[b] = keep;
-        s_kk = keep;
         s_sv[0] = Zk;
     }
     if (a.kept_ids || a.kept_probs) {
         __syncthreads();
-        const int keep = s_kk;
         const float Zk = s_sv[0];
         for (int t = tid; t < keep; t += SAMPLE_THREADS) {
-            if (a.kept_ids) a.kept_ids[(int64_t)b * SAMPLE_CAP + t] = s_si[t];
-            if (a.kept_probs) a.kept_probs[(int64_t)b * SAMPLE_CAP + t] = __fdiv_rn(s_cv[t], Zk);
+            if (a.kept_ids) a.kept_ids[(int64_t)b * SAMPLE_CAP + t] = s_ci[t];
+            if (a.kept_probs) a.kept_probs[(int64_t)b * SAMPLE_CAP + t] = s_cv[t] / Zk;
         }
     }
 }
@@ -187,7 +214,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
 int vcla_sample_launch(float* logits, int64_t ld, int B, int V, int n_hist, const int32_t* n_hist_dev, const vcla_sample_args* a,
                        int64_t* out, hipStream_t s) {
     VCLA_REQUIRE(logits && a && out, VCLA_ERR_BAD_ARG, "sample: null pointer");
-    VCLA_REQUIRE(B >= 0 && V > 0 && ld >= V && n_hist >= 0, VCLA_ERR_BAD_SHAPE, "sample: B=%d V=%d ld=%lld n_hist=%d", B, V, (long long)ld, n_hist);
+    VCLA_REQUIRE(B >= 0 && V > 0 && V <= VCLA_SAMPLE_MAX_VOCAB && ld >= V && n_hist >= 0, VCLA_ERR_BAD_SHAPE,
+                 "sample: B=%d V=%d (max %d) ld=%lld n_hist=%d", B, V, VCLA_SAMPLE_MAX_VOCAB, (long long)ld, n_hist);
     VCLA_REQUIRE(a->top_k >= 1 && a->top_k <= VCLA_SAMPLE_MAX_TOP_K, VCLA_ERR_BAD_ARG, "sample: top_k=%d outside [1, %d]", a->top_k, VCLA_SAMPLE_MAX_TOP_K);
     VCLA_REQUIRE(a->temperature > 0.f && a->repetition_penalty > 0.f && a->top_p > 0.0 && a->top_p <= 1.0 && a->no_repeat_ngram_size >= 0 &&
                  a->min_tokens_to_keep >= 1 && a->n_eos >= 0 && a->n_eos <= VCLA_SAMPLE_MAX_EOS, VCLA_ERR_BAD_ARG,

@@ -70,7 +70,7 @@ class ModelCfg(C.Structure):
     ]
 
 
-SAMPLE_MAX_TOP_K, SAMPLE_MAX_EOS, SAMPLE_KEPT_LD, SAMPLE_MAX_HIST = 256, 4, 512, 4096
+SAMPLE_MAX_TOP_K, SAMPLE_MAX_EOS, SAMPLE_KEPT_LD, SAMPLE_MAX_HIST, SAMPLE_MAX_VOCAB = 256, 4, 512, 4096, 53248
 
 
 class SampleArgs(C.Structure):

@@ -8,6 +8,8 @@ reference has them; the model object they drive is the HIP-backed VisualCLAModel
 """
 from __future__ import annotations
 
+import os
+
 import gc
 import logging
 import traceback
@@ -94,10 +96,13 @@ def attach_runtime(model: VisualCLAModel, tokenizer, image_processor):
 
 def get_model_and_tokenizer_and_processor(visualcla_model=None, text_model=None, vision_model=None, lora_model=None,
                                           torch_dtype=torch.float16, default_device=None, device_map=None,
-                                          load_in_8bit=False, gpu_preprocess=False):
+                                          load_in_8bit=False, gpu_preprocess=False, fold_lora_adapter=True):
     """-> (model, tokenizer, image_processor).  `torch_dtype=float16` (the reference default) selects the bf16
     MI355X path; float32 selects the fp32 parity mode.  `gpu_preprocess=True` (not in the reference) swaps the returned
-    CLIPImageProcessor for `preprocess.GpuClipImageProcessor`: same call, same pixels, computed on the device."""
+    CLIPImageProcessor for `preprocess.GpuClipImageProcessor`: same call, same pixels, computed on the device.
+    With text_model / vision_model / lora_model the reference returns the BASE model and its callers wrap it in
+    peft.PeftModel (inference.py:66-75, merge_llama_with_visualcla_lora.py:78-85); here the adapter found in `lora_model` is
+    folded into the weights at load (`fold_lora_adapter=False` restores the reference's base-only behaviour)."""
     from transformers import CLIPImageProcessor, LlamaTokenizer
     tokenizer = attach_special_tokens(LlamaTokenizer.from_pretrained(visualcla_model or lora_model))
     if visualcla_model is not None:
@@ -111,7 +116,9 @@ def get_model_and_tokenizer_and_processor(visualcla_model=None, text_model=None,
         model = VisualCLAModel.from_vision_text_pretrained(vision_model, text_model,
                                                            visualcla_config=VisualCLAConfig.from_pretrained(lora_model),
                                                            torch_dtype=torch_dtype, default_device=default_device,
-                                                           device_map=device_map, load_in_8bit=load_in_8bit)
+                                                           device_map=device_map, load_in_8bit=load_in_8bit,
+                                                           lora_model=lora_model if fold_lora_adapter and os.path.isfile(
+                                                               os.path.join(lora_model, "adapter_model.bin")) else None)
     image_processor = CLIPImageProcessor.from_pretrained(vision_model or visualcla_model)
     if gpu_preprocess:
         from .preprocess import GpuClipImageProcessor

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .configuration_visualcla import VisualCLAConfig
-from .weights import add_fp8_copies, extend_position_embedding, pack_state_dict, random_packed, unpack_state_dict  # noqa: F401
+from .weights import add_fp8_copies, extend_position_embedding, fold_lora, pack_state_dict, random_packed, unpack_state_dict  # noqa: F401
 
 
 def _act_dtype(torch_dtype) -> torch.dtype:
@@ -185,10 +185,13 @@ class VisualCLAModel:
     @classmethod
     def from_vision_text_pretrained(cls, vision_model_name_or_path: str = None, text_model_name_or_path: str = None,
                                     visualcla_config: Union[str, VisualCLAConfig] = None, torch_dtype=torch.float16,
-                                    default_device=None, device_map=None, load_in_8bit=False, **kwargs):
+                                    default_device=None, device_map=None, load_in_8bit=False, lora_model: str = None,
+                                    **kwargs):
         """Separate CLIP / LLaMA checkpoints + a VisualCLA config; the resampler and projection are
         random-initialised exactly as the reference does before its caller attaches LoRA weights
-        (modeling_visualcla.py:184-261).  Un-merged LoRA loading needs `peft`, which is out of scope."""
+        (modeling_visualcla.py:184-261).  `lora_model` (not in the reference, whose callers wrap the result in
+        `peft.PeftModel`, scripts/inference/inference.py:66-75) folds the un-merged release adapter into the weights at
+        load time (weights.fold_lora), since this model is not an nn.Module peft could wrap."""
         import json
         if vision_model_name_or_path is None:
             raise ValueError("If `vision_model` is not defined as an argument, a `vision_model_name_or_path` has to be defined")
@@ -219,6 +222,14 @@ class VisualCLAModel:
                 sd[p + nm + ".weight"], sd[p + nm + ".bias"] = torch.ones(Dr), torch.zeros(Dr)
         sd["image_projection_layer.weight"] = torch.randn(t["hidden_size"], Dr, generator=g) * std
         sd["image_projection_layer.bias"] = torch.zeros(t["hidden_size"])
+        if lora_model is not None:
+            cfg_path, bin_path = os.path.join(lora_model, "adapter_config.json"), os.path.join(lora_model, "adapter_model.bin")
+            if not (os.path.isfile(cfg_path) and os.path.isfile(bin_path)):
+                raise ValueError(f"'{lora_model}' holds no adapter_config.json + adapter_model.bin")
+            with open(cfg_path) as f:
+                fold_lora(sd, torch.load(bin_path, map_location="cpu", weights_only=True), json.load(f))
+            # modules_to_save grows the embeddings to the tokenizer's size (merge script :68-75)
+            visualcla_config.text_config["vocab_size"] = sd["text_model.model.embed_tokens.weight"].shape[0]
         return cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -565,7 +576,7 @@ class VisualCLAModel:
         mnt = int(getattr(gc, "min_new_tokens", None) or 0) if eos else 0
         if len(eos) > _lib.SAMPLE_MAX_EOS and mnt:
             return None
-        if n_new > _lib.SAMPLE_MAX_HIST:
+        if n_new > _lib.SAMPLE_MAX_HIST or self.config.text_config["vocab_size"] > _lib.SAMPLE_MAX_VOCAB:
             return None
         kw = dict(repetition_penalty=gc.repetition_penalty if gc.repetition_penalty is not None else 1.0,
                   no_repeat_ngram_size=gc.no_repeat_ngram_size or 0, min_new_tokens=mnt, eos_ids=eos if mnt else ())

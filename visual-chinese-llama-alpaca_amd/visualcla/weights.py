@@ -124,6 +124,63 @@ def extend_position_embedding(state_dict: Dict[str, torch.Tensor], patch_size: i
     return state_dict
 
 
+def fold_lora(state_dict: Dict[str, torch.Tensor], adapter: Dict[str, torch.Tensor], adapter_config: dict) -> Dict[str, torch.Tensor]:
+    """Fold a peft LoRA adapter (the un-merged release layout: adapter_config.json + adapter_model.bin, README_EN.md:122-133)
+    into a reference-named state dict, in place: what `PeftModel.from_pretrained(...).merge_and_unload()` does in
+    scripts/merge_llama_with_visualcla_lora.py:78-85, without peft.
+
+      * `<module>.lora_A.weight` [r, in] / `<module>.lora_B.weight` [out, r]  ->  W += (lora_alpha / r) * B @ A
+        (transposed when fan_in_fan_out), accumulated in fp32;
+      * every other adapter tensor is a `modules_to_save` module saved whole (embed_tokens / lm_head grown to the new
+        vocabulary, visual_resampler.*, image_projection_layer.*): it REPLACES the base tensor.
+    Adapter keys carry peft's `base_model.model.` prefix and, depending on the peft version, a `.default` adapter name or a
+    `modules_to_save.default.` infix; all are accepted."""
+    r = int(adapter_config["r"])
+    scale = float(adapter_config["lora_alpha"]) / r
+    fan_in_fan_out = bool(adapter_config.get("fan_in_fan_out", False))
+
+    def clean(k: str) -> str:
+        while k.startswith("base_model.model."):
+            k = k[len("base_model.model."):]
+        return k.replace(".modules_to_save.default.", ".").replace(".original_module.", ".").replace(".default.", ".")
+
+    def resolve(k: str) -> str:
+        # transformers 5.x CLIP is flat, the reference (4.x) nests vision_model.vision_model.
+        if k in state_dict:
+            return k
+        for a, b in (("vision_model.vision_model.", "vision_model."), ("vision_model.", "vision_model.vision_model.")):
+            if k.startswith(a) and b + k[len(a):] in state_dict:
+                return b + k[len(a):]
+        return k
+
+    pairs: Dict[str, Dict[str, torch.Tensor]] = {}
+    for k, v in adapter.items():
+        k = clean(k)
+        for tag in ("lora_A", "lora_B"):
+            if f".{tag}." in k:
+                pairs.setdefault(k.split(f".{tag}.")[0], {})[tag] = v
+                break
+        else:
+            state_dict[resolve(k)] = v.detach().clone()
+    for mod, ab in pairs.items():
+        if "lora_A" not in ab or "lora_B" not in ab:
+            raise KeyError(f"LoRA adapter holds only one of lora_A / lora_B for '{mod}'")
+        name = resolve(mod + ".weight")
+        if name not in state_dict:
+            raise KeyError(f"LoRA adapter targets '{mod}', which the base checkpoint does not have")
+        A, B = ab["lora_A"].float(), ab["lora_B"].float()
+        if A.shape[0] != r or B.shape[1] != r:
+            raise ValueError(f"LoRA rank mismatch for '{mod}': A {tuple(A.shape)}, B {tuple(B.shape)}, r={r}")
+        delta = (B @ A) * scale
+        if fan_in_fan_out:
+            delta = delta.t()
+        w = state_dict[name]
+        if delta.shape != w.shape:
+            raise ValueError(f"LoRA delta {tuple(delta.shape)} does not fit '{name}' {tuple(w.shape)}")
+        state_dict[name] = (w.float() + delta).to(w.dtype if w.dtype != torch.float16 else torch.float32)
+    return state_dict
+
+
 def rope_tables(max_pos: int, head_dim: int, theta: float):
     """fp32 cos/sin [max_pos, head_dim/2], computed exactly as hf:llama/modeling_llama.py:98-127 does (CPU, fp32)."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
@@ -194,6 +251,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg, device, act_dtype: torch.d
     out["proj.w"] = _pack_w(g("image_projection_layer.weight"), device)
     out["proj.b"] = _f32(g("image_projection_layer.bias"), device)
 
+    if t.get("num_hidden_layers", 0) == 0:       # vision-only context (tgwebui pipeline): no decoder tensors
+        return out
     tp = "text_model."
     out["llama.embed"] = g(tp + "model.embed_tokens.weight").to(device=device, dtype=torch.bfloat16).contiguous()
     for i in range(t["num_hidden_layers"]):
@@ -321,6 +380,8 @@ def unpack_state_dict(packed: Dict[str, torch.Tensor], cfg) -> Dict[str, torch.T
         sd[s + "output.LayerNorm.weight"], sd[s + "output.LayerNorm.bias"] = c(packed[d + "ln2.g"]), c(packed[d + "ln2.b"])
     Dt, It, V = t["hidden_size"], t["intermediate_size"], t["vocab_size"]
     sd["image_projection_layer.weight"], sd["image_projection_layer.bias"] = c(packed["proj.w"][:Dt]), c(packed["proj.b"])
+    if "llama.embed" not in packed:              # vision-only context
+        return sd
     tp = "text_model."
     sd[tp + "model.embed_tokens.weight"] = c(packed["llama.embed"])
     for i in range(t["num_hidden_layers"]):
