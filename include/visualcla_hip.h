@@ -172,11 +172,11 @@ int vcla_attention(const vcla_attn_args* args, int dtype, void* stream);
 /* Next-row N1: CLIP preprocessing of ONE uint8 HWC RGB image on the device (the reference does it on the host with
    PIL/numpy, models/visualcla/modeling_utils.py:150-152): Pillow-exact fixed-point bicubic resize (coefficient tables
    {first tap, tap count, 22-bit weights [n, kmax]} for the S cropped output columns / rows come from the host), centre
-   crop to S x S, v * rescale, (v - mean) / std (host float arrays), CHW store in the activation dtype.
+   crop to S x S, float32(float64(v) * rescale), then (x - mean) / std in float32 (host float arrays), CHW store in the activation dtype.
    tmp: H * S * 3 bytes of scratch.  mean3 / std3 are HOST pointers. */
 int vcla_image_preprocess(const uint8_t* img, int H, int W, uint8_t* tmp, int S, const int32_t* h_lo, const int32_t* h_cnt,
                           const int32_t* h_k, int h_kmax, const int32_t* v_lo, const int32_t* v_cnt, const int32_t* v_k,
-                          int v_kmax, float rescale, const float* mean3, const float* std3, void* out, int dtype,
+                          int v_kmax, double rescale, const float* mean3, const float* std3, void* out, int dtype,
                           void* stream);
 
 /* out[b, t] = table[ids[b, t]], except rows img_pos[b]+1 .. img_pos[b]+Q which take image_embeds[b, :]

@@ -98,6 +98,7 @@ def clip_preprocess(img: np.ndarray, size: int = 224, mean=CLIP_MEAN, std=CLIP_S
     oh, ow = resized_shape(h, w, size)
     r = resize_bicubic_u8(img, oh, ow)
     top, left = (oh - size) // 2, (ow - size) // 2
-    crop = r[top:top + size, left:left + size].astype(np.float32) * np.float32(1 / 255)
+    # hf:image_transforms.py rescale(): float64 multiply, then the downcast; normalize(): float32 (x - mean) / std
+    crop = (r[top:top + size, left:left + size].astype(np.float64) * (1 / 255)).astype(np.float32)
     x = (crop - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
     return np.ascontiguousarray(x.transpose(2, 0, 1))

@@ -8,7 +8,7 @@ echo "== host"; nproc; free -g | head -2; rocminfo | grep -E "Marketing|gfx|Comp
 python -c "import torch;print(torch.__version__, torch.cuda.device_count(), torch.cuda.get_device_name(0))"
 rm -f gpurun_out/parity_report.txt
 echo "== kernel parity"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
-echo "== model parity"; timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py tests/test_gpu_preprocess.py tests/test_gpu_sampling.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60
+echo "== model parity"; timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py tests/test_gpu_preprocess.py tests/test_gpu_sampling.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/model_parity.log 2>&1; tail -40 gpurun_out/model_parity.log | cut -c1-300
 if [ "$mode" != "quick" ]; then
   echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
   echo "== bench"; timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 | tee gpurun_out/bench.log

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, int S, const int32_t* __restrict__ lo,
                                                             const int32_t* __restrict__ cnt, const int32_t* __restrict__ k, int kmax,
-                                                            float rescale, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                            double rescale, float m0, float m1, float m2, float s0, float s1, float s2,
                                                             T* __restrict__ out) {
     const int y = blockIdx.x;
     const int y0 = lo[y], n = cnt[y];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
         float v;
         {
 #pragma clang fp contract(off)   // numpy rounds after the multiply and after the subtract: an FMA here is 1 ulp off
-            const float scaled = (float)acc * rescale;
+            const float scaled = (float)((double)acc * rescale);   // HF rescales in float64, then rounds to float32
             const float centred = scaled - mean;
             v = centred / sd;   // hipcc's default fp32 divide is correctly rounded
         }
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
 
 extern "C" int vcla_image_preprocess(const uint8_t* img, int H, int W, uint8_t* tmp, int S, const int32_t* h_lo,
                                      const int32_t* h_cnt, const int32_t* h_k, int h_kmax, const int32_t* v_lo,
-                                     const int32_t* v_cnt, const int32_t* v_k, int v_kmax, float rescale, const float* mean3,
+                                     const int32_t* v_cnt, const int32_t* v_k, int v_kmax, double rescale, const float* mean3,
                                      const float* std3, void* out, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "image_preprocess: bad dtype %d", dtype);
     VCLA_REQUIRE(H > 0 && W > 0 && S > 0 && h_kmax > 0 && v_kmax > 0, VCLA_ERR_BAD_SHAPE, "image_preprocess: H=%d W=%d S=%d", H, W, S);

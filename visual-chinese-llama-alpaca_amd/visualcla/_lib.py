@@ -110,7 +110,7 @@ SYMBOLS = {
     "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "vcla_attention": (_i, [C.POINTER(AttnArgs), _i, _vp]),
-    "vcla_image_preprocess": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, C.POINTER(C.c_float),
+    "vcla_image_preprocess": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), _vp, _i, _vp]),
     "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -101,7 +101,7 @@ class GpuClipImageProcessor:
         """image: PIL.Image or uint8 HWC array/tensor; out: [3, S, S] slice of the batch tensor (device, contiguous)."""
         lib = _lib.load()
         if hasattr(image, "convert"):
-            image = np.asarray(image.convert("RGB"))
+            image = np.array(image.convert("RGB"))   # a writable copy: torch.as_tensor warns on PIL's read-only buffer
         img = torch.as_tensor(image)
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("expected a uint8 HWC RGB image")

@@ -78,7 +78,7 @@ class VisionHalf:
         """`visualcla_vision_lora_model` branch (reference :62-82): base CLIP + a vision-only peft adapter, plus
         visual_resampler_config.json / visual_resampler_model.bin / image_projection_layer_model.bin saved beside it."""
         from transformers import CLIPImageProcessor
-        config = VisualCLAConfig()
+        config = VisualCLAConfig(use_visual_resampler=True)
         with open(os.path.join(clip_dir, "config.json")) as f:
             vc = json.load(f)
         config.vision_config = vc.get("vision_config", vc)
