@@ -4,7 +4,7 @@
 //   RepetitionPenaltyLogitsProcessor -> NoRepeatNGramLogitsProcessor -> MinNewTokensLengthLogitsProcessor ->
 //   TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one draw
 // (hf:generation/logits_process.py, order of hf:generation/utils.py _get_logits_processor).  The draw is the inverse CDF of
-// the kept set (descending probability, ties by index) at a caller-supplied uniform, so a run is a pure function of
+// the kept set (descending probability, ties by token id) at a caller-supplied uniform, so a run is a pure function of
 // (logits, history, uniforms).  One 1024-thread workgroup per sequence; the 200 KB fp32 logits row stays in L2 across the
 // passes.  HBM/L2-bound integer + compare work; no GEMM shape anywhere.
 #include "vcla_common.h"
@@ -13,12 +13,25 @@
 #define SAMPLE_CAP 512       // kept-set capacity: top_k <= 256 plus ties at the k-th value
 #define SAMPLE_MAX_HIST 4096 // generated tokens visible to the repetition / n-gram processors (max_position_embeddings = 2048)
 #define SAMPLE_PER_THREAD 52 // logits per thread held in registers (no spills at 128 VGPRs): V <= 53248
-#define SAMPLE_BIN_COPIES 8  // histogram replicas: spreads same-bin LDS atomics of neighbouring lanes
 
 // order-preserving float -> unsigned key (ascending)
 __device__ __forceinline__ unsigned fkey(float x) {
     const unsigned u = __float_as_uint(x);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float funkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 struct SampleParams {
@@ -45,25 +58,31 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
                                                                 const int32_t* __restrict__ n_hist_dev, SampleParams a,
                                                                 int64_t* __restrict__ out) {
     __shared__ int s_hist[SAMPLE_MAX_HIST];
-    __shared__ unsigned s_bins[256 * SAMPLE_BIN_COPIES];
+    __shared__ unsigned s_seen[VCLA_SAMPLE_MAX_VOCAB / 32];   // one bit per token id: "already penalised"
+    __shared__ int s_cnt[3];
     __shared__ float s_cv[SAMPLE_CAP], s_sv[SAMPLE_CAP];
     __shared__ int s_ci[SAMPLE_CAP], s_si[SAMPLE_CAP];
-    __shared__ unsigned s_prefix;
     __shared__ int s_kk, s_ncand;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63;
     float* x = logits + (int64_t)b * ld;
     int h = n_hist + (n_hist_dev ? *n_hist_dev : 0);
     h = h < 0 ? 0 : (h > SAMPLE_MAX_HIST ? SAMPLE_MAX_HIST : h);
     for (int i = tid; i < h; i += SAMPLE_THREADS) s_hist[i] = (int)a.history[(int64_t)i * B + b];
+    const bool penalise = a.repetition_penalty != 1.f && h > 0;
+    if (penalise)
+        for (int i = tid; i < VCLA_SAMPLE_MAX_VOCAB / 32; i += SAMPLE_THREADS) s_seen[i] = 0u;
+    if (tid < 3) s_cnt[tid] = 0;
+    if (tid == 0) s_ncand = 0;
     __syncthreads();
 
-    // ---- RepetitionPenaltyLogitsProcessor: gather / rescale / scatter, i.e. once per DISTINCT generated token
-    if (a.repetition_penalty != 1.f) {
+    // ---- RepetitionPenaltyLogitsProcessor: gather / rescale / scatter, i.e. once per DISTINCT generated token -- the
+    //      thread whose atomicOr flips the token's bit is the one that applies it
+    if (penalise) {
         for (int i = tid; i < h; i += SAMPLE_THREADS) {
             const int tok = s_hist[i];
-            bool first = tok >= 0 && tok < V;
-            for (int j = 0; j < i && first; ++j) first = s_hist[j] != tok;
-            if (first) {
+            if (tok < 0 || tok >= V) continue;
+            const unsigned bit = 1u << (tok & 31);
+            if (!(atomicOr(&s_seen[tok >> 5], bit) & bit)) {
                 const float v = x[tok];
                 x[tok] = v < 0.f ? v * a.repetition_penalty : v / a.repetition_penalty;
             }
@@ -85,93 +104,109 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
     if (tid < a.n_eos && h < a.min_new_tokens && a.eos[tid] >= 0 && a.eos[tid] < V) x[a.eos[tid]] = -INFINITY;
     __syncthreads();
 
-    // ---- TemperatureLogitsWarper on read: this thread's slice of the row goes to registers once (64 loads in flight),
-    //      the radix passes below never touch memory again
-    const float T = a.temperature;
-    float y[SAMPLE_PER_THREAD];
+    // ---- this thread's slice of the row goes to registers once (all loads in flight) as order-preserving keys of the
+    //      RAW scores; nothing below touches memory again.  Selection runs on the raw scores because dividing by the
+    //      temperature is monotone; the division itself is applied to the few candidates only.
+    unsigned key[SAMPLE_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
         const int i = tid + j * SAMPLE_THREADS;
-        y[j] = i < V ? x[i] / T : -INFINITY;
+        key[j] = i < V ? fkey(x[i]) : 0u;   // 0 sorts below every real key (fkey(-inf) = 0x007fffff)
     }
-    // ---- TopKLogitsWarper: exact k-th largest key by 4 x 8-bit radix select
-    if (tid == 0) { s_prefix = 0u; s_kk = a.top_k < V ? a.top_k : V; s_ncand = 0; }
-    unsigned mask = 0u;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 256 * SAMPLE_BIN_COPIES; i += SAMPLE_THREADS) s_bins[i] = 0u;
-        __syncthreads();
-        const unsigned prefix = s_prefix;
+    // ---- TopKLogitsWarper: bisection on the key for the largest t with count(key >= t) >= k.  A pass is 52 register
+    //      compares + a wave reduction + one LDS atomic per wave; it stops as soon as the survivors are few enough to sort
+    //      (k <= count <= 2k, at least 64), typically after ~12 passes: 8 fix the exponent, a few the mantissa.
+    const int k = a.top_k < V ? a.top_k : V;
+    const int few = 2 * k > 64 ? 2 * k : 64;   // <= SAMPLE_CAP since k <= 256
+    unsigned lo = 1u, hi = 0xffffffffu;        // count(key >= 1) = V >= k
+    for (int pass = 0; lo < hi; ++pass) {
+        const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
+        int c = 0;
 #pragma unroll
-        for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
-            const unsigned key = fkey(y[j]);
-            if (tid + j * SAMPLE_THREADS < V && (key & mask) == prefix)
-                atomicAdd(&s_bins[((key >> shift) & 255u) * SAMPLE_BIN_COPIES + (tid & (SAMPLE_BIN_COPIES - 1))], 1u);
-        }
+        for (int j = 0; j < SAMPLE_PER_THREAD; ++j) c += key[j] >= mid;
+        c = wave_sum_i(c);
+        if (lane == 0) atomicAdd(&s_cnt[pass % 3], c);
+        if (tid == 0) s_cnt[(pass + 1) % 3] = 0;   // last read two passes ago
         __syncthreads();
-        if (tid < 256) {
-            unsigned c = 0;
-#pragma unroll
-            for (int r = 0; r < SAMPLE_BIN_COPIES; ++r) c += s_bins[tid * SAMPLE_BIN_COPIES + r];
-            s_bins[tid * SAMPLE_BIN_COPIES] = c;
+        const int total = s_cnt[pass % 3];
+        if (total >= k) {
+            lo = mid;
+            if (total <= few) break;
+        } else {
+            hi = mid - 1u;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int kk = s_kk, d = 255;
-            for (; d > 0; --d) {
-                const int c = (int)s_bins[d * SAMPLE_BIN_COPIES];
-                if (c >= kk) break;
-                kk -= c;
-            }
-            s_kk = kk;
-            s_prefix = prefix | ((unsigned)d << shift);
-        }
-        mask |= 255u << shift;
-        __syncthreads();
     }
-    // ---- kept candidates: everything >= the k-th value (HF removes `scores < kth`, so ties stay), -inf never
-    const unsigned thr = s_prefix;
+    // ---- candidates: every key >= lo - 4 ulp (a superset of the top k: x1 < x2 can still give x1 / T == x2 / T, and such
+    //      a tie with the k-th divided score must survive like any other); -inf never.  Wave-aggregated compaction.
+    const unsigned lo_c = lo > 0x00800004u ? lo - 4u : 0x00800000u;
 #pragma unroll
     for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
-        if (fkey(y[j]) >= thr && y[j] > -INFINITY) {   // slots past V hold -inf
-            const int slot = atomicAdd(&s_ncand, 1);
-            if (slot < SAMPLE_CAP) { s_cv[slot] = y[j]; s_ci[slot] = tid + j * SAMPLE_THREADS; }
+        const bool take = key[j] >= lo_c && key[j] > 0x007fffffu;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, __popcll(m));
+            base = __shfl(base, 0, 64);
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (take && slot < SAMPLE_CAP) { s_cv[slot] = funkey(key[j]) / a.temperature; s_ci[slot] = tid + j * SAMPLE_THREADS; }
         }
     }
     __syncthreads();
-    const int nc = s_ncand < SAMPLE_CAP ? s_ncand : SAMPLE_CAP;
+    const int nc0 = s_ncand < SAMPLE_CAP ? s_ncand : SAMPLE_CAP;
     // rank sort, descending value; ties in DESCENDING index = the reverse of the stable ascending sort HF's top-p cut walks
     // (torch.sort on the scores), so a cut that falls inside a group of equal scores drops the lower token ids first
-    for (int t = tid; t < nc; t += SAMPLE_THREADS) {
+    for (int t = tid; t < nc0; t += SAMPLE_THREADS) {
         const float v = s_cv[t];
         const int idx = s_ci[t];
         int rank = 0;
-        for (int j = 0; j < nc; ++j) rank += (s_cv[j] > v) || (s_cv[j] == v && s_ci[j] > idx);
+        for (int j = 0; j < nc0; ++j) rank += (s_cv[j] > v) || (s_cv[j] == v && s_ci[j] > idx);
         s_sv[rank] = v;
         s_si[rank] = idx;
     }
     __syncthreads();
+    // HF removes `scores < k-th largest`: survivors are the sorted prefix down to the last score equal to the k-th
+    if (nc0 > k) {
+        const float kth = s_sv[k - 1];
+        for (int t = tid + k - 1; t < nc0; t += SAMPLE_THREADS)
+            if (s_sv[t] == kth && (t + 1 == nc0 || s_sv[t + 1] < kth)) s_ncand = t + 1;
+    }
+    __syncthreads();
+    const int nc = nc0 > k ? s_ncand : nc0;
     if (nc == 0) {   // every logit is -inf / NaN: nothing to draw from
         if (tid == 0) { out[b] = 0; if (a.n_kept) a.n_kept[b] = 0; }
         return;
     }
     const float vmax = s_sv[0];
-    for (int t = tid; t < nc; t += SAMPLE_THREADS) s_cv[t] = expf(s_sv[t] - vmax);
+    for (int t = tid; t < SAMPLE_CAP; t += SAMPLE_THREADS) s_cv[t] = t < nc ? expf(s_sv[t] - vmax) : 0.f;
     __syncthreads();
-    if (tid == 0) {
-        // ---- TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is cut, at least min_keep survive
+    // ---- TopPLogitsWarper in wave 0: lane L owns sorted ranks [8L, 8L + 8); sums by shuffle scans
+    constexpr int E = SAMPLE_CAP / 64;
+    if (tid < 64) {
+        float e[E], part = 0.f;
+#pragma unroll
+        for (int q = E - 1; q >= 0; --q) { e[q] = s_cv[lane * E + q]; part += e[q]; }
         int keep = nc;
         if (a.use_top_p) {
-            float Z = 0.f;
-            for (int r = nc - 1; r >= 0; --r) Z += s_cv[r];
-            float c = 0.f;
-            keep = 0;
-            for (int r = nc - 1; r >= 0; --r) {
-                c += s_cv[r] / Z;
-                if (c > a.top_p_complement) { keep = r + 1; break; }
+            const float Z = wave_sum_f(part);
+            // ascending cumulative probability = suffix sums over the descending order; the cut keeps every rank whose
+            // suffix sum exceeds 1 - top_p (suffix sums fall with rank, so that is a prefix)
+            float suf = part / Z;   // -> sum of the lanes above
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float up = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += up;
             }
+            float c = suf - part / Z;
+            int cnt = 0;
+#pragma unroll
+            for (int q = E - 1; q >= 0; --q) {
+                c += e[q] / Z;
+                cnt += (lane * E + q < nc) && c > a.top_p_complement;
+            }
+            keep = wave_sum_i(cnt);
             if (keep < a.min_keep) keep = a.min_keep < nc ? a.min_keep : nc;
         }
-        s_kk = keep;
+        if (lane == 0) s_kk = keep;
     }
     __syncthreads();
     const int keep = s_kk;
@@ -185,28 +220,42 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
         s_ci[rank] = idx;
     }
     __syncthreads();
-    // s_cv (exp of the value) is constant inside a tie group, so it is already in the final order
-    if (tid == 0) {
-        float Zk = 0.f;
-        for (int r = 0; r < keep; ++r) Zk += s_cv[r];
+    // s_cv (exp of the score) is constant inside a tie group, so it already is in the final order
+    if (tid < 64) {
+        float e[E], part = 0.f;
+#pragma unroll
+        for (int q = 0; q < E; ++q) { e[q] = lane * E + q < keep ? s_cv[lane * E + q] : 0.f; part += e[q]; }
+        const float Zk = wave_sum_f(part);
         const float u = a.uniforms ? a.uniforms[(int64_t)h * B + b] : 0.f;
         const float target = u * Zk;
-        float c = 0.f;
-        int pick = keep - 1;
-        for (int r = 0; r < keep; ++r) {
-            c += s_cv[r];
-            if (c > target) { pick = r; break; }
+        float pre = part;   // -> inclusive prefix over lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float dn = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += dn;
         }
-        out[b] = s_ci[pick];
-        if (a.n_kept) a.n_kept[b] = keep;
-        s_sv[0] = Zk;
-    }
-    if (a.kept_ids || a.kept_probs) {
-        __syncthreads();
-        const float Zk = s_sv[0];
-        for (int t = tid; t < keep; t += SAMPLE_THREADS) {
-            if (a.kept_ids) a.kept_ids[(int64_t)b * SAMPLE_CAP + t] = s_ci[t];
-            if (a.kept_probs) a.kept_probs[(int64_t)b * SAMPLE_CAP + t] = s_cv[t] / Zk;
+        float c = pre - part;
+        int below = 0;      // ranks whose inclusive cumulative sum is still <= target: the pick is the first one above
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            c += e[q];
+            below += (lane * E + q < keep) && !(c > target);
+        }
+        int pick = wave_sum_i(below);
+        pick = pick < keep ? pick : keep - 1;
+        if (lane == 0) {
+            out[b] = s_ci[pick];
+            if (a.n_kept) a.n_kept[b] = keep;
+        }
+        if (a.kept_ids || a.kept_probs) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int t = lane * E + q;
+                if (t < keep) {
+                    if (a.kept_ids) a.kept_ids[(int64_t)b * SAMPLE_CAP + t] = s_ci[t];
+                    if (a.kept_probs) a.kept_probs[(int64_t)b * SAMPLE_CAP + t] = e[q] / Zk;
+                }
+            }
         }
     }
 }
