@@ -182,6 +182,26 @@ def main():
                     t = timeit(run, reps=10) / 4
                     print(f"k{fk}{'f' if frag else ' '} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
                 del ws, wfs
+    if "panel" in which:
+        import os
+        print(f"== panel split-K kernel (fragment-major W), M=64, env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_PANEL")))
+        skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        from visualcla.weights import to_fragment_major
+        tot = 0.0
+        for M in (64,):
+            for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
+                a = rnd(M, K)
+                ws = [packw(N, K) for _ in range(4)]
+                wfs = [to_fragment_major(w) for w in ws]
+                out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+                def run():
+                    for w, wf in zip(ws, wfs):
+                        _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=8, splitk_ws=skws, w_frag=wf)
+                t = timeit(run, reps=10) / 4
+                tot += t
+                print(f"k8f {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s")
+                del ws, wfs
+        print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s over the 404 MB of layer weights)")
     if "gemv" in which:
         print("== GEMV (decode, weight streaming)")
         for M in (1, 4, 8):

@@ -429,7 +429,12 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
 // writes fp32 partial tiles to a workspace and gemm_panel_reduce_kernel applies the epilogue (fixed summation order).
 // (Measured alternative, round 1: reducing inside the launch -- last-arriver ticket, agent-scope release fence per
 // workgroup -- made the kernel 20 us slower (23.9 -> 44.7 us at M=64): the per-workgroup L2 write-back costs far more
-// than the ~5 us second launch.  Kept as two launches.)
+// than the ~5 us second launch.  Kept as two launches.
+// Also measured and dropped (M = 64, the four LLaMA decode GEMMs of a layer, 128 us total with this kernel): an 8-deep
+// register ring (154 us: 342 VGPRs -> 1 workgroup per CU), 512 / 768 workgroups via more K slices (156 / 158 us: the fp32
+// partial traffic grows faster than the latency hiding), and a stream-K launch that deals exactly 2 equal runs of K tiles to
+// every CU (142 us).  PMC (profiles/r01_pmc_panel_m64.txt): no LDS bank conflicts, HBM reads = algorithmic bytes, MFMA
+// busy 10 % -- what is left is per-launch ramp (~7 us on 12-44 us kernels) and the partial round trip.)
 #define PN_BN 128
 #define PN_RING 4
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
@@ -498,19 +503,20 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
     struct AReg { u32x4_t c0, c1, c2, c3; };  // up to 4 chunks per thread; unused members are never touched (NA < 4)
     AReg ra0, ra1, ra2, ra3;
     u32x4_t rw0[4], rw1[4], rw2[4], rw3[4];  // [kk*2 + j]
-    // tiles past the end of the slice re-load the last tile with ZEROED weight fragments: the MFMAs then add 0 and the
-    // ring needs no control flow (the slice length need not be a multiple of 4)
+    // tiles past the end of the slice fetch nothing and get ZEROED weight fragments (the MFMAs then add 0; the A slot keeps
+    // stale data): the slice length need not be a multiple of 4.  (Re-loading the last tile instead cost ~5 %: 135 -> 128 us
+    // for the four M = 64 decode GEMMs of a layer.)
 #define PN_LOAD(tile_, RA, RW)                                                                      \
     {                                                                                               \
-        const bool valid_ = (tile_) < nkc;                                                          \
-        const int64_t ko_ = (int64_t)(valid_ ? (tile_) : nkc - 1) * GM_BK;                          \
-        RA.c0 = *reinterpret_cast<const u32x4_t*>(asrc0 + ko_);                                       \
-        if (NA >= 2) RA.c1 = *reinterpret_cast<const u32x4_t*>(asrc1 + ko_);                          \
-        if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
-        _Pragma("unroll") for (int q = 0; q < NWL; ++q) {                                           \
-            const u32x4_t w_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(                 \
-                wsrc[q & 1] + (int64_t)(valid_ ? (tile_) : nkc - 1) * WTILE + (q >> 1) * WSTEP));   \
-            RW[q] = valid_ ? w_ : u32x4_t{0u, 0u, 0u, 0u};                                          \
+        if ((tile_) < nkc) { /* wave-uniform: past the end nothing is fetched, the slot just holds zero weights */ \
+            const int64_t ko_ = (int64_t)(tile_) * GM_BK;                                           \
+            RA.c0 = *reinterpret_cast<const u32x4_t*>(asrc0 + ko_);                                   \
+            if (NA >= 2) RA.c1 = *reinterpret_cast<const u32x4_t*>(asrc1 + ko_);                      \
+            if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
+            _Pragma("unroll") for (int q = 0; q < NWL; ++q)                                         \
+                RW[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc[q & 1] + (int64_t)(tile_) * WTILE + (q >> 1) * WSTEP)); \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < NWL; ++q) RW[q] = u32x4_t{0u, 0u, 0u, 0u};        \
         }                                                                                           \
     }
 #define PN_STORE(RA, buf_)                                                                          \
