@@ -131,6 +131,15 @@ typedef struct vcla_gemm_args {
     const void* W_q8;
     const void* W_q8_frag;
     const float* w_scale;
+    /* optional fused "next RMSNorm" (LLaMA batch decode: o_proj / down_proj feed input_layernorm / post_attention_layernorm,
+       hf:llama/modeling_llama.py:300-320): after C (residual included) is stored, also store
+       post_norm_out[m, :] = post_norm_gamma * round(C[m, :] * rstd(C[m, :])), exactly what vcla_rmsnorm would compute
+       from C.  Fused into the split-K reduction of the panel kernel; every other kernel runs vcla_rmsnorm afterwards.
+       Needs epilogue NONE, out_f32 0, no row regrouping, N <= 8192. */
+    const float* post_norm_gamma;
+    float post_norm_eps;
+    void* post_norm_out;
+    int64_t post_norm_ld;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

@@ -533,3 +533,33 @@ def test_gemm_auto_dispatch_ragged_m(lib, M, N, K, epi):
     lib.gemm(a.to(DEV, torch.bfloat16), _pack(w), N, bias=bias.to(DEV), residual=xd, out=xd, epilogue=epi,
              splitk_ws=torch.zeros(32 << 20, dtype=torch.uint8, device=DEV))
     _cmp(f"gemm_auto_ragged[{M}x{N}x{K},epi{epi}]", xd, ref, atol=2e-3, rtol=8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,frag", [(64, 4096, 4096, True), (64, 4096, 11008, True), (33, 512, 1024, False), (7, 256, 512, True),
+                                        (128, 1000, 256, True), (300, 512, 256, False), (1, 4096, 4096, False)])
+def test_gemm_post_norm_is_the_rmsnorm_of_its_own_output(lib, M, N, K, frag):
+    """post_norm_*: fused into the panel kernel's split-K reduction (M <= 128 with a workspace), a trailing vcla_rmsnorm
+    launch otherwise -- either way C must equal the plain GEMM's C and post_norm_out must equal vcla_rmsnorm(C) bit for bit"""
+    from visualcla.weights import to_fragment_major
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * 0.05
+    wp = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16, device=DEV)
+    wp[:N] = w.to(DEV, torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    wf = to_fragment_major(wp) if frag else None
+    plain = lib.gemm(a, wp, N, residual=res, splitk_ws=ws, w_frag=wf)
+    h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    fused = lib.gemm(a, wp, N, residual=res, splitk_ws=ws, w_frag=wf, post_norm_gamma=gamma, post_norm_eps=1e-6, post_norm_out=h)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain)
+    assert torch.equal(h, lib.rmsnorm(plain, gamma, 1e-6))
+    # in place over the residual, as the decoder layer calls it
+    x = res.clone()
+    lib.gemm(a, wp, N, residual=x, out=x, splitk_ws=ws, w_frag=wf, post_norm_gamma=gamma, post_norm_eps=1e-6, post_norm_out=h)
+    torch.cuda.synchronize()
+    assert torch.equal(x, plain)
+    with pytest.raises(ValueError):
+        lib.gemm(a, wp, N, epilogue=1, post_norm_gamma=gamma, post_norm_eps=1e-6, post_norm_out=h)

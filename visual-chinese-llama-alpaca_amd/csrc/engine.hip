@@ -378,8 +378,10 @@ static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry poin
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
                 int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f,
-                const WVar* wv = nullptr) {
+                const WVar* wv = nullptr, const float* post_gamma = nullptr, float post_eps = 0.f, void* post_out = nullptr,
+                int64_t post_ld = 0) {
     vcla_gemm_args a{};
+    a.post_norm_gamma = post_gamma; a.post_norm_eps = post_eps; a.post_norm_out = post_out; a.post_norm_ld = post_ld;
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32;
     a.c_group_rows = grp_rows; a.c_group_stride = grp_stride; a.c_row_offset = row_off;
@@ -488,7 +490,8 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
 // ------------------------------------------------------------------ LLaMA decoder
 // One decoder layer over M = B*T rows held in ws.x (updated in place).
 static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const LlamaWs& w, int l, int B, int T, int pos0,
-                       const int32_t* pos_dev, void* kv_cache, int ctx_max, const int32_t* key_mask) {
+                       const int32_t* pos_dev, void* kv_cache, int ctx_max, const int32_t* key_mask, bool h_ready = false,
+                       const float* next_gamma = nullptr) {
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const size_t e = esz(ctx);
@@ -498,10 +501,13 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     char* vc = kc + per;
     // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
     const bool fused = (dt == VCLA_F32) ? (M <= 8) : (M == 1);  // must mirror vcla_gemm's kernel choice
+    // Otherwise the norms ride on the producing GEMM (post_norm_*: fused into the split-K reduction for M <= 128, a plain
+    // vcla_rmsnorm launch behind the big tiles): o_proj emits post_attention_layernorm(x) and down_proj emits the NEXT
+    // layer's input_layernorm(x) -- or the final norm -- into w.h.  `h_ready`: w.h already holds this layer's ln1(x).
     if (fused) {
         RUN(gemm(ctx, s, w.x, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, L.ln1g, c.t_eps, &L.vqkv));
     } else {
-        RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
+        if (!h_ready) RUN(vcla_rmsnorm(w.x, D, L.ln1g, w.h, D, M, D, c.t_eps, dt, s));
         RUN(gemm(ctx, s, w.h, D, L.wqkv, nullptr, nullptr, 0, w.qkv, 3 * D, M, 3 * D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vqkv));
     }
     const float scale = 1.0f / sqrtf((float)d);
@@ -521,14 +527,16 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         a.Tk = pos0 + T;
         RUN(vcla_attention(&a, dt, s));
     }
-    RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vo));
     if (fused) {
+        RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vo));
         RUN(gemm(ctx, s, w.x, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, L.ln2g, c.t_eps, &L.vgu));
+        RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vd));
     } else {
-        RUN(vcla_rmsnorm(w.x, D, L.ln2g, w.h, D, M, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.ao, D, L.wo, nullptr, w.x, D, w.x, D, M, D, D, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vo, L.ln2g, c.t_eps, w.h, D));
         RUN(gemm(ctx, s, w.h, D, L.wgu, nullptr, nullptr, 0, w.act, c.t_inter, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, 0, 0, 0, nullptr, 0.f, &L.vgu));
+        RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vd, next_gamma,
+                 c.t_eps, next_gamma ? w.h : nullptr, D));
     }
-    RUN(gemm(ctx, s, w.act, c.t_inter, L.wd, nullptr, w.x, D, w.x, D, M, D, c.t_inter, VCLA_EPI_NONE, 0, 0, 0, 0, nullptr, 0.f, &L.vd));
     return VCLA_OK;
 }
 
@@ -551,11 +559,14 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     g_splitk_ws = w.splitk;
     VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < c.t_layers; ++l) {
-        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, T, pos0, nullptr, kv_cache, ctx_max, key_mask));
+        // every layer's down_proj also emits the next norm into w.h (the final norm only when all rows need it)
+        const float* next_gamma = l + 1 < c.t_layers ? ctx->llama[l + 1].ln1g : (all_logits ? ctx->norm_g : nullptr);
+        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, T, pos0, nullptr, kv_cache, ctx_max, key_mask, l > 0, next_gamma));
         RUN(tap_copy(layer_tap, l, w.x, (size_t)M * D * e, s));
     }
+    const bool norm_fused = (dt == VCLA_F32) ? (M <= 8) : (M == 1);   // llama_layer's GEMV mode ignores next_gamma
     if (all_logits) {
-        RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, M, D, c.t_eps, dt, s));
+        if (norm_fused) RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, M, D, c.t_eps, dt, s));
         RUN(tap_copy(layer_tap, c.t_layers, w.h, (size_t)M * D * e, s));
         if (logits)
             RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, logits, c.t_vocab, M, c.t_vocab, D, VCLA_EPI_NONE, 1));
@@ -574,14 +585,14 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
     RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));
-    for (int l = 0; l < c.t_layers; ++l)
-        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask));
+    for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
+        RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
+                        l + 1 < c.t_layers ? ctx->llama[l + 1].ln1g : ctx->norm_g));
     float* lg = logits ? logits : w.logits;
     if ((dt == VCLA_F32) ? (B <= 8) : (B == 1)) {
         RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps, &ctx->vlm));
     } else {
-        RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.hl, D, B, D, c.t_eps, dt, s));
-        RUN(gemm(ctx, s, w.hl, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
+        RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
     }
     if (ids_out && samp) RUN(vcla_sample_launch(lg, c.t_vocab, B, c.t_vocab, n_hist0, pos_dev, samp, ids_out, s));
     else if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));

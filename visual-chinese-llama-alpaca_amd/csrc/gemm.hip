@@ -436,6 +436,7 @@ static int launch_skinny(const vcla_gemm_args* a, hipStream_t s) {
 // every CU (142 us).  PMC (profiles/r01_pmc_panel_m64.txt): no LDS bank conflicts, HBM reads = algorithmic bytes, MFMA
 // busy 10 % -- what is left is per-launch ramp (~7 us on 12-44 us kernels) and the partial round trip.)
 #define PN_BN 128
+#define VCLA_POST_NORM_DONE (-12345)   // internal: the launcher already produced post_norm_out
 #define PN_RING 4
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
 __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
     struct AReg { u32x4_t c0, c1, c2, c3; };  // up to 4 chunks per thread; unused members are never touched (NA < 4)
     AReg ra0, ra1, ra2, ra3;
     u32x4_t rw0[4], rw1[4], rw2[4], rw3[4];  // [kk*2 + j]
-    // tiles past the end of the slice fetch nothing and get ZEROED weight fragments (the MFMAs then add 0; the A slot keeps
-    // stale data): the slice length need not be a multiple of 4.  (Re-loading the last tile instead cost ~5 %: 135 -> 128 us
+    // tiles past the end of the slice fetch nothing and get ZEROED operands (the MFMAs then add 0): the slice length need
+    // not be a multiple of 4.  (Re-loading the last tile instead cost ~5 %: 135 -> 128 us
     // for the four M = 64 decode GEMMs of a layer.)
 #define PN_LOAD(tile_, RA, RW)                                                                      \
     {                                                                                               \
@@ -515,7 +516,10 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
             if (NA >= 4) { RA.c2 = *reinterpret_cast<const u32x4_t*>(asrc2 + ko_); RA.c3 = *reinterpret_cast<const u32x4_t*>(asrc3 + ko_); } \
             _Pragma("unroll") for (int q = 0; q < NWL; ++q)                                         \
                 RW[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc[q & 1] + (int64_t)(tile_) * WTILE + (q >> 1) * WSTEP)); \
-        } else {                                                                                    \
+        } else { /* zero BOTH operands: an uninitialised A register may hold NaN bits, and 0 * NaN = NaN */ \
+            RA.c0 = u32x4_t{0u, 0u, 0u, 0u};                                                        \
+            if (NA >= 2) RA.c1 = u32x4_t{0u, 0u, 0u, 0u};                                           \
+            if (NA >= 4) { RA.c2 = u32x4_t{0u, 0u, 0u, 0u}; RA.c3 = u32x4_t{0u, 0u, 0u, 0u}; }      \
             _Pragma("unroll") for (int q = 0; q < NWL; ++q) RW[q] = u32x4_t{0u, 0u, 0u, 0u};        \
         }                                                                                           \
     }
@@ -633,6 +637,51 @@ __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(vcla_gemm_args a
         }
 }
 
+// split-K reduction of one output row per workgroup + residual + store, then the NEXT layer norm of that row in the same
+// launch (post_norm_*): the row is staged in LDS exactly as rmsnorm_kernel stages it, and the statistics / rounding follow
+// that kernel instruction for instruction, so fused and unfused paths are bit-identical.
+#define PN_NORM_MAX 8192
+#define PN_MAX_SPLITK 8
+template <typename OutT>
+__global__ __launch_bounds__(1024) void gemm_panel_reduce_norm_kernel(vcla_gemm_args a, int splitk, int n_pad, const float* __restrict__ partial) {
+    __shared__ float row[PN_NORM_MAX];
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* rp = a.residual ? (const bf16_t*)a.residual + (int64_t)m * a.ldr : nullptr;
+    OutT* cp = (OutT*)a.C + (int64_t)m * a.ldc;
+    for (int n = tid * 4; n < a.N; n += 1024 * 4) {
+        float4 p[PN_MAX_SPLITK];   // every slice's load in flight before the first add
+#pragma unroll
+        for (int s = 0; s < PN_MAX_SPLITK; ++s)
+            p[s] = s < splitk ? *reinterpret_cast<const float4*>(partial + ((int64_t)s * a.M + m) * n_pad + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float x[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < PN_MAX_SPLITK; ++s) { x[0] += p[s].x; x[1] += p[s].y; x[2] += p[s].z; x[3] += p[s].w; }   // slice order, as the plain reduce
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= a.N) break;
+            float v = x[r];
+            if (a.w_scale) v *= a.w_scale[n + r];
+            if (a.bias) v += a.bias[n + r];
+            if (rp) v += bf2f(rp[n + r]);
+            v = Act<OutT>::rnd(v);
+            Act<OutT>::st(cp + n + r, v);
+            row[n + r] = v;
+        }
+    }
+    __syncthreads();
+    // statistics exactly as rmsnorm_kernel: 256 strided partial sums (threads 0..255), wave sums, 4-term total
+    float q = 0.f;
+    if (tid < 256)
+        for (int c = tid; c < a.N; c += 256) q += row[c] * row[c];
+    q = wave_sum(q);
+    if ((tid & 63) == 0 && tid < 256) red[tid >> 6] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.N + a.post_norm_eps);
+    OutT* yr = (OutT*)a.post_norm_out + (int64_t)m * a.post_norm_ld;
+    for (int c = tid; c < a.N; c += 1024) Act<OutT>::st(yr + c, a.post_norm_gamma[c] * Act<OutT>::rnd(row[c] * rstd));
+}
+
 static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
     const int tiles_n = (a->N + PN_BN - 1) / PN_BN, nk = a->K / GM_BK;
     int s = (320 + tiles_n / 2) / tiles_n;
@@ -653,6 +702,13 @@ static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
     else if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, 1><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     else gemm_panel_kernel<EPI, OutT, MT, 0><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     VCLA_CHECK_LAUNCH("gemm_panel_kernel");
+    if constexpr (EPI == VCLA_EPI_NONE) {
+        if (splitk > 1 && splitk <= PN_MAX_SPLITK && a->post_norm_gamma) {   // vcla_gemm checked the preconditions and skips its own rmsnorm launch
+            gemm_panel_reduce_norm_kernel<OutT><<<a->M, 1024, 0, s>>>(*a, splitk, n_pad, (const float*)a->splitk_ws);
+            VCLA_CHECK_LAUNCH("gemm_panel_reduce_norm_kernel");
+            return VCLA_POST_NORM_DONE;
+        }
+    }
     if (splitk > 1) {
         const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
         const int64_t work = (int64_t)a->M * ((n_out + 3) / 4);
@@ -1235,8 +1291,22 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
     }
 }
 
+static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream);
+
 extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(a, VCLA_ERR_BAD_ARG, "gemm: null args");
+    if (a->post_norm_gamma) {
+        VCLA_REQUIRE(a->post_norm_out && a->epilogue == VCLA_EPI_NONE && !a->out_f32 && a->c_group_rows <= 0 && a->N <= PN_NORM_MAX &&
+                         a->post_norm_ld >= a->N, VCLA_ERR_BAD_ARG,
+                     "gemm: post_norm needs post_norm_out, epilogue NONE, activation-dtype C, no row regrouping, N <= %d", PN_NORM_MAX);
+    }
+    const int rc = gemm_impl(a, dtype, stream);
+    if (rc == VCLA_POST_NORM_DONE) return VCLA_OK;
+    if (rc || !a->post_norm_gamma || a->M == 0) return rc;
+    return vcla_rmsnorm(a->C, a->ldc, a->post_norm_gamma, a->post_norm_out, a->post_norm_ld, a->M, a->N, a->post_norm_eps, dtype, stream);
+}
+
+static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
     VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
@@ -1273,8 +1343,9 @@ extern "C" int vcla_gemm(const vcla_gemm_args* a, int dtype, void* stream) {
                     tail.C = (char*)a->C + (size_t)head.M * a->ldc * cs;
                     if (a->residual) tail.residual = (const char*)a->residual + (size_t)head.M * a->ldr * es;
                     head.force_kernel = 4;
-                    int rc = vcla_gemm(&head, dtype, stream);
-                    return rc ? rc : vcla_gemm(&tail, dtype, stream);
+                    head.post_norm_gamma = tail.post_norm_gamma = nullptr;   // the wrapper normalises all of C afterwards
+                    int rc = gemm_impl(&head, dtype, stream);
+                    return rc ? rc : gemm_impl(&tail, dtype, stream);
                 }
             }
             kernel = prefer_256(a) ? 4 : 1;

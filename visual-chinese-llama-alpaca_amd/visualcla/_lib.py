@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
         ("W_frag", C.c_void_p),
         ("W_q8", C.c_void_p), ("W_q8_frag", C.c_void_p), ("w_scale", C.c_void_p),
+        ("post_norm_gamma", C.c_void_p), ("post_norm_eps", C.c_float), ("post_norm_out", C.c_void_p), ("post_norm_ld", C.c_int64),
     ]
 
 
@@ -207,7 +208,8 @@ def rmsnorm(x, gamma, eps, out=None):
 
 
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
-         group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None):
+         group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None,
+         post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out]."""
     lib = load()
     M, K = a.shape
@@ -229,6 +231,9 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args.W_q8, args.W_q8_frag, args.w_scale = ptr(w_q8), ptr(w_q8_frag), ptr(w_scale)
     args.splitk_ws = ptr(splitk_ws)
     args.splitk_ws_bytes = splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0
+    if post_norm_gamma is not None:
+        args.post_norm_gamma, args.post_norm_eps = ptr(post_norm_gamma), float(post_norm_eps)
+        args.post_norm_out, args.post_norm_ld = ptr(post_norm_out), post_norm_out.stride(0)
     check(lib.vcla_gemm(C.byref(args), dtype_code(a.dtype), stream_ptr()))
     return out
 
