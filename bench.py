@@ -234,7 +234,7 @@ def main():
         }
         res["breakdown_ms"] = breakdown
         res["roofline"] = gemv_roofline(model) if not args.fp8 else None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported by the N=1 run only
             try:
                 res["cpu_baseline"] = cpu_baseline(model, cfg_o, args.prompt_len, args.new_tokens, args.cpu_tokens)
             except Exception as e:  # e.g. host RAM too small for the 27 GB fp32 copy
