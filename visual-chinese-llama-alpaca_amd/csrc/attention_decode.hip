@@ -7,6 +7,7 @@
 // P V: each wave owns every 4th key, lanes own 2 adjacent dims, partial outputs reduced through LDS.
 // Position / context length come from device memory (pos0 + *pos_dev) so the launch is hipGraph-replayable.
 #include "vcla_common.h"
+#include <stdlib.h>
 
 template <typename T, int D> struct RowDot;
 template <int D> struct RowDot<float, D> {
@@ -50,7 +51,11 @@ template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& 
     const uint32_t t = *reinterpret_cast<const uint32_t*>(p); a = __uint_as_float(t << 16); b = __uint_as_float(t & 0xffff0000u);
 }
 
-template <typename T, int D>
+// COOP = false: one key per thread (all of a head's K rows in flight after one instruction burst: best when the launch is a
+// few dozen workgroups, B = 1).  COOP = true: D/8 adjacent lanes share a key row, so every load instruction of a wave
+// covers 64/(D/8) whole rows = 8 full cache lines instead of 64 partial ones -- with thousands of workgroups (batch decode)
+// the per-CU texture path, not latency, is what the one-key-per-thread form saturates.
+template <typename T, int D, bool COOP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                           T* __restrict__ out, int H, int ctx_max, int pos0,
@@ -91,24 +96,64 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
-    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS): one key per thread, 16-byte row loads.
-    // (A/B on MI355X, profiles/r01: a lane-group-per-row variant with shuffle folds was 13.3 us vs 9.2 us for this form at
-    // B = 1 and equal at B = 64, where the kernel runs at the KV-streaming rate either way.)
+    // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS)
     const int Tk = pos + 1;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
     float mx = -INFINITY;
-    for (int j = tid; j < Tk; j += 256) {
-        float sv;
-        if (km && km[j] == 0) sv = -INFINITY;
-        else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
-        else {
+    if constexpr (!COOP) {
+        for (int j = tid; j < Tk; j += 256) {
+            float sv;
+            if (km && km[j] == 0) sv = -INFINITY;
+            else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
+            else {
+                float acc = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < D; ++c) acc += qs[c] * knew[c];
+                sv = scale * acc;
+            }
+            sc[j] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    } else {
+        constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW, UK = 4;
+        const int kc_ = lane % LPK, ksub = wave * KPW + lane / LPK;
+        float qr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[e] = qs[kc_ * 8 + e];
+        for (int j0 = ksub; j0 < pos; j0 += KPB * UK) {
+            float kk[UK][8];
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                const int j = j0 + u * KPB;
+                if (j < pos) load8<T>(kbase + (int64_t)j * D + kc_ * 8, kk[u]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kk[u][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += qr[e] * kk[u][e];
+#pragma unroll
+                for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+                const int j = j0 + u * KPB;
+                if (kc_ == 0 && j < pos) {
+                    const float sv = (km && km[j] == 0) ? -INFINITY : scale * acc;
+                    sc[j] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        }
+        if (tid == 0) {   // the new key
             float acc = 0.f;
 #pragma unroll 8
             for (int c = 0; c < D; ++c) acc += qs[c] * knew[c];
-            sv = scale * acc;
+            const float sv = (km && km[pos] == 0) ? -INFINITY : scale * acc;
+            sc[pos] = sv;
+            mx = fmaxf(mx, sv);
         }
-        sc[j] = sv;
-        mx = fmaxf(mx, sv);
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -184,8 +229,14 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
     const size_t lds = (size_t)(3 * D + 8 + 4 * D + sc_cap) * sizeof(float);
     VCLA_REQUIRE(lds <= 64 * 1024, VCLA_ERR_BAD_SHAPE, "attn_decode: ctx_max=%d needs %zu B of LDS (max 64 KiB)", ctx_max, lds);
     dim3 grid(H, B);
-    attn_decode_kernel<T, D><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
-                                                    pos_dev, key_mask, key_mask_ld, scale, sc_cap);
+    static const int coop_env = getenv("VCLA_ATTN_COOP") ? atoi(getenv("VCLA_ATTN_COOP")) : -1;   // -1 auto, 0 / 1 force (A/B runs)
+    const bool coop = coop_env >= 0 ? coop_env != 0 : (int64_t)B * H >= 512;
+    if (coop)
+        attn_decode_kernel<T, D, true><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
+                                                              pos_dev, key_mask, key_mask_ld, scale, sc_cap);
+    else
+        attn_decode_kernel<T, D, false><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
+                                                               pos_dev, key_mask, key_mask_ld, scale, sc_cap);
     VCLA_CHECK_LAUNCH("attn_decode_kernel");
     return VCLA_OK;
 }
