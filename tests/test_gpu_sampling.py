@@ -184,3 +184,30 @@ def test_top_p_cut_inside_a_tie_group_matches_the_oracle_convention():
     logits[0, [5, 9, 20, 33, 40, 41]] = [3.0, 1.0, 1.0, 1.0, 1.0, 2.0]
     for top_p in (0.75, 0.8, 0.85, 0.9, 0.95):
         _check(logits, np.zeros((0, 1), np.int64), S.SampleCfg(top_k=50, top_p=top_p), np.array([0.97], np.float32))
+
+
+def test_streaming_path_uses_the_device_sampler_and_matches_the_graph_loop():
+    """stopping criteria (what chat_in_stream installs) force the host-driven loop; token selection there is the same
+    kernel, so for the same uniforms the two loops must emit the same tokens -- and HF's own processors must agree on greedy"""
+    from transformers import GenerationConfig, StoppingCriteria, StoppingCriteriaList
+    cfg, W, model, px, ids, mask = _model_and_inputs()
+    seen = []
+
+    class Spy(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kw):
+            seen.append(input_ids.shape)
+            return False
+
+    gc = GenerationConfig(max_new_tokens=9, do_sample=True, top_p=0.9, top_k=40, temperature=0.5, repetition_penalty=1.1,
+                          no_repeat_ngram_size=3, eos_token_id=None)
+    torch.manual_seed(77)
+    loop = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=gc)
+    torch.manual_seed(77)
+    stepped = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=gc,
+                             stopping_criteria=StoppingCriteriaList([Spy()]))
+    assert torch.equal(loop, stepped) and seen == [(2, i + 1) for i in range(9)]
+    g2 = GenerationConfig(max_new_tokens=9, do_sample=False, repetition_penalty=1.2, no_repeat_ngram_size=2, eos_token_id=None)
+    dev = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=g2, stopping_criteria=StoppingCriteriaList([Spy()]))
+    host = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=g2, stopping_criteria=StoppingCriteriaList([Spy()]),
+                          device_sampling=False)
+    assert torch.equal(dev, host)

@@ -634,11 +634,11 @@ class VisualCLAModel:
 
         plain_greedy = not procs and not gc.do_sample
         samp_kw = None
-        if not plain_greedy and not logits_processor and not criteria and device_sampling is not False:
+        if not plain_greedy and not logits_processor and device_sampling is not False:
             samp_kw = self._device_sampling(gc, n_new)
         if device_sampling and samp_kw is None and not plain_greedy:
-            raise ValueError("device_sampling=True but the generation config needs the host path (custom processors, "
-                             "stopping criteria, or top_k outside [1, %d])" % _lib.SAMPLE_MAX_TOP_K)
+            raise ValueError("device_sampling=True but the generation config needs HF's processors on the host-driven path "
+                             "(custom logits_processor, or top_k outside [1, %d])" % _lib.SAMPLE_MAX_TOP_K)
         fast = not criteria and (plain_greedy or samp_kw is not None)
         if fast:
             # ---- device-resident loop: argmax, or the on-device sampler, feeds the next step
@@ -688,22 +688,35 @@ class VisualCLAModel:
                 toks = toks[:, :max(keep, 1)]
             return toks
 
-        # ---- general path: host-driven, one decode step per token; processors / sampling / callbacks in torch
-        generated = torch.empty(B, 0, dtype=torch.int64, device=self._device)
+        # ---- general path: host-driven, one decode step per token (stopping criteria / streaming callbacks see every token).
+        # Token selection is still ONE kernel per step (vcla_argmax / vcla_sample) unless the caller brought its own
+        # logits processors or a config the device sampler does not cover: then HF's processor classes + torch.multinomial.
+        hist = torch.empty(n_new, B, dtype=torch.int64, device=self._device)       # step-major, what the sampler reads
+        generated = hist[:0].t()
         done = torch.zeros(B, dtype=torch.bool, device=self._device)
         eos_t = torch.tensor(eos, device=self._device) if eos else None
         step_logits = torch.empty(B, t["vocab_size"], dtype=torch.float32, device=self._device)
+        dev_select = not logits_processor and device_sampling is not False and (plain_greedy or samp_kw is not None)
+        samp = None
+        if dev_select and not plain_greedy:
+            self._uniforms = torch.rand(n_new, B, device=self._device) if gc.do_sample else None
+            samp = _lib.sample_args(uniforms=self._uniforms, history=hist, **samp_kw)
         for step in range(n_new):
             scores = logits
-            for p in procs:
-                scores = p(generated, scores)
-            if gc.do_sample:
-                probs = torch.softmax(scores, dim=-1)
-                nxt = torch.multinomial(probs, num_samples=1)[:, 0]
+            if dev_select:
+                with torch.cuda.device(self._device):
+                    nxt = _lib.argmax(logits) if plain_greedy else _lib.sample(logits, samp, n_hist=step)
             else:
-                nxt = scores.argmax(dim=-1)
+                for p in procs:
+                    scores = p(generated, scores)
+                if gc.do_sample:
+                    probs = torch.softmax(scores, dim=-1)
+                    nxt = torch.multinomial(probs, num_samples=1)[:, 0]
+                else:
+                    nxt = scores.argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
-            generated = torch.cat([generated, nxt[:, None]], dim=1)
+            hist[step] = nxt
+            generated = hist[:step + 1].t()
             if eos_t is not None:
                 done = done | torch.isin(nxt, eos_t)
             stop = False
@@ -720,4 +733,4 @@ class VisualCLAModel:
                                                       cache.kv.data_ptr(), ctx_max, _lib.ptr(key_mask),
                                                       step_logits.data_ptr(), None, ws.data_ptr(), ws.numel(), stream))
             logits = step_logits
-        return generated
+        return generated.contiguous()
