@@ -3,8 +3,8 @@
 // Replaces three launches (rope + append, attention) and the q/k round trip through HBM.  HBM-bound: the only
 // large reads are the K and V rows of the cache (ctx * d * 2 elements per head), each read exactly once.
 //
-// Workgroup = one (b, h), 256 threads.  Scores: one key per thread (16-byte row loads), probabilities in LDS;
-// P V: each wave owns every 4th key, lanes own 2 adjacent dims, partial outputs reduced through LDS.
+// Workgroup = one (b, h), 256 threads.  Scores: one key per thread (B = 1) or D/8 lanes per key row (batch decode), 16-byte
+// row loads, probabilities in LDS; P V: D/8 adjacent lanes own one value row, partial outputs reduced by shuffles + LDS.
 // Position / context length come from device memory (pos0 + *pos_dev) so the launch is hipGraph-replayable.
 #include "vcla_common.h"
 #include <stdlib.h>
@@ -42,14 +42,6 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float* 
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) { bf8_to_f32(*reinterpret_cast<const uint4*>(p), v); }
-
-template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
-template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
-    const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y;
-}
-template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& a, float& b) {
-    const uint32_t t = *reinterpret_cast<const uint32_t*>(p); a = __uint_as_float(t << 16); b = __uint_as_float(t & 0xffff0000u);
-}
 
 // COOP = false: one key per thread (all of a head's K rows in flight after one instruction burst: best when the launch is a
 // few dozen workgroups, B = 1).  COOP = true: D/8 adjacent lanes share a key row, so every load instruction of a wave
