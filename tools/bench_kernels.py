@@ -202,6 +202,23 @@ def main():
                 print(f"k8f {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s")
                 del ws, wfs
         print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s over the 404 MB of layer weights)")
+    if "gemv1" in which:
+        import os
+        print("== M=1 GEMV on the decode shapes, rotating over 8 weight buffers (HBM-resident); env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_GEMV1")))
+        tot = 0.0
+        for tag, N, K, epi, fused in (("qkv", 12288, 4096, 0, True), ("o", 4096, 4096, 0, False), ("gate-up", 22016, 4096, 3, True), ("down", 4096, 11008, 0, False)):
+            ws = [packw(N, K) for _ in range(8)]
+            x = rnd(1, K)
+            gamma = torch.ones(K, device=DEV) if fused else None
+            out = torch.empty(1, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+            def run():
+                for w in ws:
+                    _lib.gemm(x, w, N, epilogue=epi, out=out, force_kernel=2, norm_gamma=gamma, norm_eps=1e-6)
+            t = timeit(run, reps=10) / 8
+            tot += t
+            print(f"gemv1 {tag:8s} N={N:6d} K={K:6d}  {t*1e6:8.2f} us  {N*K*2/t/1e9:8.1f} GB/s")
+            del ws
+        print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s)")
     if "gemv" in which:
         print("== GEMV (decode, weight streaming)")
         for M in (1, 4, 8):
