@@ -229,8 +229,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if not args.fp8 else ("bf16 activations / fp32 accumulate, fp8-e4m3 decode weights" if B == 1 else
-                      "bf16 (fp8 copies loaded, but batch decode streams the bf16 fragment-major twin: the fp8 panel kernel is slower)"), "data": "synthetic (random-init 7B weights, N(0,1) pixels, synthetic ids)",
+            "dtype": "bf16" if not args.fp8 else "bf16 activations / fp32 accumulate, fp8-e4m3 decode weights", "data": "synthetic (random-init 7B weights, N(0,1) pixels, synthetic ids)",
             "config": {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
                                     f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if args.sample else 'greedy'} decode "
                                     f"(BASELINE configs[{1 if B == 1 else 2}])"),

@@ -185,13 +185,15 @@ def test_state_dict_roundtrip_and_dtype_switch():
     assert (b - ref).abs().max().item() <= 1e-3 and (a - ref).abs().max().item() <= 6e-2
 
 
-def test_fp8_decode_weights_match_oracle_on_dequantised_weights(golden_dir):
-    """BASELINE configs[4] weight path: fp8 (e4m3fn) copies serve the M = 1 decode GEMVs, prefill stays bf16.  The decode-step
-    logits must equal the oracle evaluated the same way (prefill on W, decode steps on the DEQUANTISED matrices)."""
+@pytest.mark.parametrize("nb", [1, 2])
+def test_fp8_decode_weights_match_oracle_on_dequantised_weights(golden_dir, nb):
+    """BASELINE configs[4] weight path: fp8 (e4m3fn) copies serve the decode steps (M = 1 GEMV, M > 1 panel kernel), prefill stays
+    bf16.  The decode-step logits must equal the oracle evaluated the same way (prefill on W, decode steps on the DEQUANTISED
+    matrices)."""
     from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows, pad_to
     from transformers import LogitsProcessorList
     g, cfg, W, px, ids, mask, n_new = _setup("small_b2", golden_dir)
-    px, ids, mask = px[:1], ids[:1], mask[:1]
+    px, ids, mask = px[:nb], ids[:nb], mask[:nb]
     m = make_hip_model(cfg, W, torch.bfloat16)
     m.enable_fp8_decode()
     assert m.fp8_decode
@@ -218,7 +220,7 @@ def test_fp8_decode_weights_match_oracle_on_dequantised_weights(golden_dir):
     past = ids.shape[1]
     for s_ in range(3):
         e = W["text_model.model.embed_tokens.weight"][toks[:, s_]][:, None, :]
-        h = O.llama_forward(e, Wq, cfg.text, torch.ones(1, past + 1, dtype=torch.int64), cache, past)
+        h = O.llama_forward(e, Wq, cfg.text, torch.ones(nb, past + 1, dtype=torch.int64), cache, past)
         ref_steps.append(O.lm_head(h, Wq)[:, 0])
         past += 1
     for s_ in range(4):
@@ -277,3 +279,36 @@ def test_7b_decode_equals_forward_and_batch_invariance(model_7b):
     _report(f"7B: permuted-batch agreement {agree_perm:.2f}, solo agreement {agree_solo:.2f}")
     assert agree_perm == 1.0            # same M, same kernels, same per-row arithmetic -> bit identical
     assert agree_solo >= 0.5            # M=1 uses the same GEMV kernel family; allow bf16 near-ties
+
+
+def test_set_image_size_retargets_the_vision_tower(golden_dir):
+    """BASELINE configs[4] patching (336 px at 7B; 84 px = 6x6 patches here): the position embedding grows bicubically
+    (weights.extend_position_embedding), every kernel is generic in the token count, fp8 copies survive the re-pack"""
+    import copy
+    from visualcla.weights import extend_position_embedding
+    g, cfg, W, px, ids, mask, n_new = _setup("tiny_b2", golden_dir)
+    m = make_hip_model(cfg, W, torch.float32)
+    big = cfg.vision.image_size + 2 * cfg.vision.patch_size
+    m.set_image_size(big)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.vision.image_size = big
+    W2 = {k: v.clone() for k, v in W.items()}
+    extend_position_embedding(W2, cfg.vision.patch_size, big)
+    px2, ids2, mask2 = O.make_inputs(cfg2, 2, ids.shape[1])
+    got = m.forward(input_ids=ids2.cuda(), pixel_values=px2.cuda(), attention_mask=mask2.cuda()).logits.float().cpu()
+    want = O.visualcla_forward(ids2, px2, mask2, W2, cfg2)
+    want = want["logits"] if isinstance(want, dict) else want
+    err = (got - want).abs().max().item()
+    _report(f"set_image_size({big}) fp32 logits max err {err:.3e}")
+    assert err <= 1e-3
+    with pytest.raises(ValueError):                       # the old resolution is now refused, like the reference's CLIP
+        m.embed_images(px.cuda())
+    with pytest.raises(ValueError):
+        m.set_image_size(big + 3)                         # not a multiple of the patch size
+    mb = make_hip_model(cfg, W, torch.bfloat16)
+    mb.enable_fp8_decode()
+    mb.set_image_size(big)
+    assert mb.fp8_decode
+    toks = mb.generate(input_ids=ids2.cuda(), pixel_values=px2.cuda(), attention_mask=mask2.cuda(), max_new_tokens=3, do_sample=False,
+                       eos_token_id=None)
+    assert toks.shape == (2, 3)

@@ -187,8 +187,8 @@ def main():
         print(f"== panel split-K kernel (fragment-major W), M=64, env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_PANEL")))
         skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
         from visualcla.weights import to_fragment_major
-        tot = 0.0
-        for M in (64,):
+        tot = tot8 = 0.0
+        for M in (int(os.environ.get("VCLA_BENCH_M", "64")),):
             for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
                 a = rnd(M, K)
                 ws = [packw(N, K) for _ in range(4)]
@@ -200,8 +200,17 @@ def main():
                 t = timeit(run, reps=10) / 4
                 tot += t
                 print(f"k8f {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s")
-                del ws, wfs
-        print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s over the 404 MB of layer weights)")
+                from visualcla.weights import quantize_fp8_rows, to_fragment_pair_major_fp8
+                qs = [quantize_fp8_rows(w) for w in ws]
+                qfs = [to_fragment_pair_major_fp8(q) for q, _ in qs]
+                def run8():
+                    for w, (q, sc), qf in zip(ws, qs, qfs):
+                        _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=8, splitk_ws=skws, w_q8=q, w_q8_frag=qf, w_scale=sc)
+                t8 = timeit(run8, reps=10) / 4
+                tot8 += t8
+                print(f"k8q {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t8*1e6:8.1f} us  {N*K/t8/1e9:8.1f} GB/s (fp8 bytes)")
+                del ws, wfs, qs, qfs
+        print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s over the 404 MB of layer weights); fp8 copies: {tot8*1e6:.1f} us")
     if "gemv1" in which:
         import os
         print("== M=1 GEMV on the decode shapes, rotating over 8 weight buffers (HBM-resident); env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_GEMV1")))

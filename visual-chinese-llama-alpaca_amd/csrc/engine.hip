@@ -374,6 +374,7 @@ extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
 
 // ------------------------------------------------------------------ small wrappers
 static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry points from their workspace carve
+static thread_local bool g_decode_step = false;   // inside decode_step_impl: the fp8 weight copies (if loaded) may be used
 
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
@@ -389,9 +390,10 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
     a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
     if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)
-        // fp8 copies pay off in the M = 1 GEMV (1.3x end to end); the fp8 panel kernel is correct but currently slower than
-        // the bf16 fragment-major one (half the bytes in flight per lane) -> batch decode keeps bf16 weights
-        if (M == 1 && wv->q8 && wv->q8f && wv->s8) { a.W_q8 = wv->q8; a.W_q8_frag = wv->q8f; a.w_scale = wv->s8; }
+        // fp8 copies (when loaded) serve the DECODE steps only (g_decode_step; a short prefill keeps the bf16 values): half the HBM
+        // bytes.  M = 1 GEMV: 1.3x end to end; panel kernel: 112 vs 132 us per layer at
+        // M = 64, 88 vs 111 us at M = 32 (tools/bench_kernels.py panel, after the fetch-past-the-slice fix)
+        if (g_decode_step && wv->q8 && wv->q8f && wv->s8) { a.W_q8 = wv->q8; a.W_q8_frag = wv->q8f; a.w_scale = wv->s8; }
         else a.W_frag = wv->frag;
     }
     return vcla_gemm(&a, ctx->c.act_dtype, s);
@@ -584,6 +586,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
+    struct Scope { Scope() { g_decode_step = true; } ~Scope() { g_decode_step = false; } } decode_scope;
     RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));
     for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,

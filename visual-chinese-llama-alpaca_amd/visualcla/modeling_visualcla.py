@@ -316,11 +316,14 @@ class VisualCLAModel:
             return self
         if image_size % v["patch_size"]:
             raise ValueError(f"image_size {image_size} is not a multiple of the patch size {v['patch_size']}")
+        had_fp8 = self.fp8_decode
         sd = self.state_dict()
         extend_position_embedding(sd, v["patch_size"], image_size)
         v["image_size"] = image_size
         self.vision_model.config.image_size = image_size
         self._packed = pack_state_dict(sd, self.config, self._device, self._dtype)
+        if had_fp8:
+            add_fp8_copies(self._packed)      # re-packing drops the derived copies
         self._ws.clear()
         self._build_ctx()
         return self
