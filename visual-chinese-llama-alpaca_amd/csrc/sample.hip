@@ -5,8 +5,9 @@
 //   TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one draw
 // (hf:generation/logits_process.py, order of hf:generation/utils.py _get_logits_processor).  The draw is the inverse CDF of
 // the kept set (descending probability, ties by token id) at a caller-supplied uniform, so a run is a pure function of
-// (logits, history, uniforms).  One 1024-thread workgroup per sequence; the 200 KB fp32 logits row stays in L2 across the
-// passes.  HBM/L2-bound integer + compare work; no GEMM shape anywhere.
+// (logits, history, uniforms).  One 1024-thread workgroup per sequence; after the penalties the 200 KB fp32 logits row is
+// read ONCE into registers (52 order-preserving keys per thread) and every later pass is register compares.  Integer +
+// compare work, bound by one CU's issue rate and a handful of barriers (42 us per step); no GEMM shape anywhere.
 #include "vcla_common.h"
 
 #define SAMPLE_THREADS 1024
@@ -23,12 +24,6 @@ __device__ __forceinline__ unsigned fkey(float x) {
 __device__ __forceinline__ float funkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
         for (int q = E - 1; q >= 0; --q) { e[q] = s_cv[lane * E + q]; part += e[q]; }
         int keep = nc;
         if (a.use_top_p) {
-            const float Z = wave_sum_f(part);
+            const float Z = wave_sum(part);
             // ascending cumulative probability = suffix sums over the descending order; the cut keeps every rank whose
             // suffix sum exceeds 1 - top_p (suffix sums fall with rank, so that is a prefix)
             float suf = part / Z;   // -> sum of the lanes above
@@ -225,7 +220,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
         float e[E], part = 0.f;
 #pragma unroll
         for (int q = 0; q < E; ++q) { e[q] = lane * E + q < keep ? s_cv[lane * E + q] : 0.f; part += e[q]; }
-        const float Zk = wave_sum_f(part);
+        const float Zk = wave_sum(part);
         const float u = a.uniforms ? a.uniforms[(int64_t)h * B + b] : 0.f;
         const float target = u * Zk;
         float pre = part;   // -> inclusive prefix over lanes
