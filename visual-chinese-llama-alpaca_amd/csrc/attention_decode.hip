@@ -43,6 +43,22 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float* 
 }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) { bf8_to_f32(*reinterpret_cast<const uint4*>(p), v); }
 
+// 8 consecutive elements of a cache row, still in the storage dtype: lets the V rows be FETCHED before the softmax (the loads
+// do not depend on the scores) and converted afterwards
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void get(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+template <> struct Raw8<bf16_t> {
+    uint4 t;
+    __device__ __forceinline__ void load(const bf16_t* p) { t = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { t = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void get(float* v) const { bf8_to_f32(t, v); }
+};
+
 // COOP = false: one key per thread (all of a head's K rows in flight after one instruction burst: best when the launch is a
 // few dozen workgroups, B = 1).  COOP = true: D/8 adjacent lanes share a key row, so every load instruction of a wave
 // covers 64/(D/8) whole rows = 8 full cache lines instead of 64 partial ones -- with thousands of workgroups (batch decode)
@@ -88,6 +104,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
+    // ---- V rows of the first P V pass are requested NOW: their latency overlaps the score / softmax phase below
+    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW, UV = 8;
+    const int vc_ = lane % LPK, vsub = wave * KPW + lane / LPK;   // chunk of the row, key slot within a block pass
+    Raw8<T> vpre[UV];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+        const int j = vsub + u * KPB;
+        if (j < pos) vpre[u].load(vbase + (int64_t)j * D + vc_ * 8);   // predicated: no traffic for slots past the context
+        else vpre[u].zero();
+    }
+
     // ---- scores over cached keys 0..pos-1 (from HBM) and the new key (from LDS)
     const int Tk = pos + 1;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
@@ -107,8 +134,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
             mx = fmaxf(mx, sv);
         }
     } else {
-        constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW, UK = 4;
-        const int kc_ = lane % LPK, ksub = wave * KPW + lane / LPK;
+        constexpr int UK = 4;
+        const int kc_ = vc_, ksub = vsub;
         float qr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) qr[e] = qs[kc_ * 8 + e];
@@ -171,30 +198,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     // ---- P V.  LPK = D/8 adjacent lanes own the 8-dim chunks of ONE value row (16-byte loads, a full row per lane group),
     // so a wave covers 64/LPK keys per load instruction and the workgroup 4x that; every thread just accumulates its 8 dims
     // over its keys -- all loads of a pass are independent (one HBM latency per 8 keys in flight per thread).
-    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW;
-    const int vc_ = lane % LPK, vsub = wave * KPW + lane / LPK;   // chunk of the row, key slot within a block pass
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    constexpr int UV = 8;
-    for (int j0 = vsub; j0 < pos; j0 += KPB * UV) {
-        float vv[UV][8];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {   // pass 0: the rows fetched before the softmax
+        const int j = vsub + u * KPB;
+        const float pj = j < pos ? sc[j] : 0.f;
+        float vv[8];
+        vpre[u].get(vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pj * vv[e];
+    }
+    for (int j0 = vsub + KPB * UV; j0 < pos; j0 += KPB * UV) {
+        Raw8<T> vr[UV];
         float pj[UV];
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
             const int j = j0 + u * KPB;
             const bool ok = j < pos;
             pj[u] = ok ? sc[j] : 0.f;
-            if (ok) load8<T>(vbase + (int64_t)j * D + vc_ * 8, vv[u]);      // predicated: no traffic for slots past the context
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
-            }
+            if (ok) vr[u].load(vbase + (int64_t)j * D + vc_ * 8);
+            else vr[u].zero();
         }
 #pragma unroll
-        for (int u = 0; u < UV; ++u)
+        for (int u = 0; u < UV; ++u) {
+            float vv[8];
+            vr[u].get(vv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += pj[u] * vv[u][e];
+            for (int e = 0; e < 8; ++e) o[e] += pj[u] * vv[e];
+        }
     }
     if (vsub == 0) {  // the new token's value comes from LDS
 #pragma unroll
