@@ -102,11 +102,12 @@ def gemv_roofline(model, n_rep: int = 20):
             "launches_timed": launches}
 
 
-def cpu_baseline(model, cfg_o, prompt_len: int, new_tokens: int, sample_tokens: int):
+def cpu_baseline(model, prompt_len: int, new_tokens: int, sample_tokens: int):
     """The CPU oracle (kind 'port': oracle/visualcla_oracle.py, fp32, torch CPU kernels on all host cores) on a bounded
     sample of the same request: 1 image through the vision stack + prefill of the T=128 prompt + `sample_tokens` decode
     steps; tokens/s is scaled to the full 128-token request as 128 / (t_vision + t_prefill + 128 * t_step)."""
-    from oracle import visualcla_oracle as O
+    from oracle import visualcla_oracle as O   # the ONLY place this file touches oracle/: the CPU leg is the oracle, timed
+    cfg_o = O.cfg_7b()
     # one NUMA domain's worth of threads: torch's CPU kernels collapse when spread over all 256 SMT threads of the
     # GPU box's 2-socket host (measured: 28 s/token at 256 threads)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -153,25 +154,22 @@ def main():
     dev = torch.device("cuda", local)
 
     import visualcla
-    from oracle import visualcla_oracle as O
     from visualcla.distributed import gather_tokens, shard_range
-    from tests.helpers import stub_tokenizer
+    from visualcla.synthetic import make_inputs, stub_tokenizer
 
     cfg = visualcla.visualcla_7b_config()
-    cfg_o = O.cfg_7b()
     model = visualcla.VisualCLAModel.from_random(cfg, device=dev, torch_dtype=torch.bfloat16, seed=0)
-    model.tokenizer = stub_tokenizer(cfg_o)
+    model.tokenizer = stub_tokenizer()
     model.image_at_head = False
     if args.fp8:
         model.enable_fp8_decode()
     if args.image_size != 224:
         model.set_image_size(args.image_size)
-        cfg_o.vision.image_size = args.image_size
 
     B = args.batch
     gB = B * world
     lo, hi = shard_range(gB, rank, world)
-    px, ids, mask = O.make_inputs(cfg_o, gB, args.prompt_len)          # same global batch on every rank; take my shard
+    px, ids, mask = make_inputs(model.config, gB, args.prompt_len)      # same global batch on every rank; take my shard
     px, ids, mask = px[lo:hi].to(dev, torch.bfloat16), ids[lo:hi].to(dev), mask[lo:hi].to(dev)
     kw = dict(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=args.new_tokens, do_sample=False,
               eos_token_id=None, use_graph=not args.no_graph)
@@ -240,7 +238,7 @@ def main():
         res["roofline"] = gemv_roofline(model) if not args.fp8 else None
         if not args.no_cpu_baseline and world == 1 and args.image_size == 224:   # the CPU baseline is reported by the N=1 run only
             try:
-                res["cpu_baseline"] = cpu_baseline(model, cfg_o, args.prompt_len, args.new_tokens, args.cpu_tokens)
+                res["cpu_baseline"] = cpu_baseline(model, args.prompt_len, args.new_tokens, args.cpu_tokens)
             except Exception as e:  # e.g. host RAM too small for the 27 GB fp32 copy
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -227,3 +227,23 @@ def test_tgwebui_pipeline_statics_and_missing_settings():
     assert T.get_pipeline_from_model_name("llama-13b", {}) is None
     with pytest.raises(KeyError):
         T.get_pipeline("visualcla-7b", {})
+
+
+def test_benchmark_input_generator_matches_the_oracle_recipe():
+    """bench.py draws its requests from visualcla.synthetic (product side); same seeds -> same tensors as the oracle's generator"""
+    import visualcla
+    from visualcla.synthetic import make_inputs, stub_tokenizer
+    cfg_o = O.cfg_7b()
+    want = O.make_inputs(cfg_o, 3, 128)
+    got = make_inputs(visualcla.visualcla_7b_config(), 3, 128)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    tok = stub_tokenizer()
+    assert (tok.img_start_token_id, tok.img_end_token_id, tok.img_token_id) == (cfg_o.img_start_token_id, cfg_o.img_end_token_id, cfg_o.img_token_id)
+    small = to_vcla_config(O.cfg_tiny())
+    c = O.cfg_tiny()
+    got = make_inputs(small, 2, 24, img_ids=(c.img_start_token_id, c.img_end_token_id, c.img_token_id))
+    for a, b in zip(got, O.make_inputs(c, 2, 24)):
+        assert torch.equal(a, b)
+    px = make_inputs(visualcla.visualcla_7b_config(), 1, 128, image_size=336)[0]
+    assert px.shape == (1, 3, 336, 336)

@@ -200,6 +200,11 @@ def main():
                 t = timeit(run, reps=10) / 4
                 tot += t
                 print(f"k8f {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s")
+                def run1():   # no workspace -> one K slice per column tile, epilogue in the kernel, no reduce launch
+                    for w, wf in zip(ws, wfs):
+                        _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=8, splitk_ws=None, w_frag=wf)
+                t1 = timeit(run1, reps=10) / 4
+                print(f"k8f {tag:8s} (no split-K)               {t1*1e6:8.1f} us  {N*K*2/t1/1e9:8.1f} GB/s")
                 from visualcla.weights import quantize_fp8_rows, to_fragment_pair_major_fp8
                 qs = [quantize_fp8_rows(w) for w in ws]
                 qfs = [to_fragment_pair_major_fp8(q) for q, _ in qs]

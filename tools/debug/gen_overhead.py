@@ -2,12 +2,11 @@
 import cProfile, pstats, sys, time, torch
 sys.path.insert(0, "."); sys.path.insert(0, "visual-chinese-llama-alpaca_amd")
 import visualcla
-from oracle import visualcla_oracle as O
-from tests.helpers import stub_tokenizer
-cfg = visualcla.visualcla_7b_config(); cfg_o = O.cfg_7b()
+from visualcla.synthetic import make_inputs, stub_tokenizer
+cfg = visualcla.visualcla_7b_config()
 m = visualcla.VisualCLAModel.from_random(cfg, device="cuda:0", torch_dtype=torch.bfloat16, seed=0)
-m.tokenizer = stub_tokenizer(cfg_o); m.image_at_head = False
-px, ids, mask = O.make_inputs(cfg_o, 1, 128)
+m.tokenizer = stub_tokenizer(); m.image_at_head = False
+px, ids, mask = make_inputs(cfg, 1, 128)
 px, ids, mask = px.cuda().bfloat16(), ids.cuda(), mask.cuda()
 kw = dict(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=128, do_sample=False, eos_token_id=None)
 for _ in range(2): m.generate(**kw)
