@@ -14,6 +14,7 @@
 //                      non-temporal loads, 4 rows per wave, wave-shuffle reduction.  HBM-bound by design.
 //   gemm_f32_kernel    fp32 activations (parity mode): classic 64x64x16 LDS-tiled FMA kernel.
 #include "vcla_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ shared epilogue math
 template <int EPI> __device__ __forceinline__ float epi_act(float x) {
@@ -448,16 +449,26 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
 }
 
 // WMODE: 0 = W row-major bf16, 1 = fragment-major bf16 (W_frag), 2 = fragment-pair-major fp8 (W_q8_frag + w_scale)
-template <int EPI, typename OutT, int MT, int WMODE>
-__global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
+// KG = K groups per workgroup (1 or 2).  KG = 2: 8 waves; waves 4..7 repeat the column assignment of waves 0..3 on the second
+// half of the workgroup's K slice (own A buffers), the two accumulator sets meet in LDS and group 0 runs the epilogue.  Twice
+// the waves (= loads in flight) per CU at the same grid, half the split-K partials for the same number of K streams: the
+// launch can then stay at <= 256 workgroups (one per CU, no second round) and the big-N GEMMs need no partials at all.
+template <int EPI, typename OutT, int MT, int WMODE, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
     constexpr int NA = (MT * 128 + 255) / 256;  // 16-byte A chunks per thread per K tile
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][MT * 16 * 128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char As_all[KG][2][MT * 16 * 128];
+    const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    auto& As = As_all[kg];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * PN_BN, ks = blockIdx.y;
     const int nk = a.K / GM_BK;
-    const int t_beg = (int)((int64_t)ks * nk / splitk), t_end = (int)((int64_t)(ks + 1) * nk / splitk);
-    const int nkc = t_end - t_beg;     // K tiles of this slice (>= 1: host guarantees splitk <= nk)
+    const int s_beg = (int)((int64_t)ks * nk / splitk), s_end = (int)((int64_t)(ks + 1) * nk / splitk);
+    // this K group's part of the slice; the loop trip count follows group 0 (the longer one), group 1 pads with zero tiles
+    const int len0 = KG == 1 ? s_end - s_beg : (s_end - s_beg + 1) / 2;
+    const int t_beg = kg == 0 ? s_beg : s_beg + len0;
+    const int nkc = kg == 0 ? len0 : (s_end - s_beg) - len0;     // K tiles of this group (group 1 may have 0)
+    const int nkc_loop = len0;
     const bf16_t* Ag = (const bf16_t*)a.A + (int64_t)t_beg * GM_BK;
     const bf16_t* Wg = (const bf16_t*)a.W + (int64_t)t_beg * GM_BK;
 
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
     PN_LOAD(0, ra0, rw0) PN_LOAD(1, ra1, rw1) PN_LOAD(2, ra2, rw2) PN_LOAD(3, ra3, rw3)
     PN_STORE(ra0, 0)
     __syncthreads();
-    const int nk4 = (nkc + PN_RING - 1) / PN_RING * PN_RING;
+    const int nk4 = (nkc_loop + PN_RING - 1) / PN_RING * PN_RING;
     for (int kt = 0; kt < nk4; kt += PN_RING) {
         // tile kt+t: MFMAs from LDS buffer t&1 and ring slot t; park tile kt+t+1 (loaded 3 steps ago) in the other LDS
         // buffer; refill slot t with tile kt+t+4; one barrier per tile
@@ -568,6 +579,26 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(vcla_gemm_args a, int s
 #undef PN_LOAD
 #undef PN_STORE
 #undef PN_COMPUTE
+    if constexpr (KG == 2) {
+        // group 1 hands its accumulators over through LDS (the A buffers are free after the last barrier): [i][j][thread]
+        static_assert(KG == 1 || sizeof(As_all) >= (size_t)MT * 2 * 256 * 16, "accumulator hand-over must fit the A buffers");
+        f32x4_t* xch = reinterpret_cast<f32x4_t*>(&As_all[0][0][0]);
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xch[(i * 2 + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4_t o = xch[(i * 2 + j) * 256 + tid];
+                acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+            }
+    }
     if (splitk == 1) {
         gemm_epilogue<EPI, OutT, MT, 2>(a, acc, 0, n0 + wave * 32, lane);
     } else {
@@ -696,8 +727,30 @@ static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
 template <int EPI, typename OutT, int MT>
 static int launch_panel_mt(const vcla_gemm_args* a, hipStream_t s) {
     const int n_pad = (a->N + 127) / 128 * 128;
-    const int splitk = panel_splitk(a, n_pad);
-    dim3 grid((a->N + PN_BN - 1) / PN_BN, splitk);
+    int splitk = panel_splitk(a, n_pad);
+    const int tiles_n = (a->N + PN_BN - 1) / PN_BN;
+    // 8-wave form (two K groups per workgroup): fragment-major weights (bf16 or fp8), M <= 64, at most one workgroup per CU
+    static const int kg_env = getenv("VCLA_PANEL_KG") ? atoi(getenv("VCLA_PANEL_KG")) : 2;
+    bool kg2 = false;
+    if constexpr (MT <= 4) {
+        if (kg_env == 2 && (a->W_frag || a->W_q8_frag) && tiles_n <= 256) {
+            int s2 = 256 / tiles_n;                    // <= 256 workgroups: every CU gets at most one, no second round
+            const int nk = a->K / GM_BK;
+            static const int s2max = getenv("VCLA_PANEL_S2MAX") ? atoi(getenv("VCLA_PANEL_S2MAX")) : 8;
+            if (s2 > s2max) s2 = s2max;
+            if (s2 > nk / 2) s2 = nk / 2 > 0 ? nk / 2 : 1;   // each K group wants at least one tile
+            while (s2 > 1 && (size_t)s2 * a->M * n_pad * 4 > a->splitk_ws_bytes) --s2;
+            if (!a->splitk_ws) s2 = 1;
+            if (tiles_n * s2 >= 128) { kg2 = true; splitk = s2; }   // small problems keep the 4-wave form (more workgroups)
+        }
+    }
+    dim3 grid(tiles_n, splitk);
+    if (kg2) {
+        if constexpr (MT <= 4) {
+            if (a->W_q8_frag) gemm_panel_kernel<EPI, OutT, MT, 2, 2><<<grid, 512, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+            else gemm_panel_kernel<EPI, OutT, MT, 1, 2><<<grid, 512, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
+        }
+    } else
     if (a->W_q8_frag) gemm_panel_kernel<EPI, OutT, MT, 2><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     else if (a->W_frag) gemm_panel_kernel<EPI, OutT, MT, 1><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
     else gemm_panel_kernel<EPI, OutT, MT, 0><<<grid, 256, 0, s>>>(*a, splitk, n_pad, (float*)a->splitk_ws);
