@@ -136,27 +136,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
             mx = fmaxf(mx, sv);
         }
     } else {
-        constexpr int UK = 4;
+        constexpr int UK = 8;   // 8 key rows per lane group in flight (raw, converted at use)
         const int kc_ = vc_, ksub = vsub;
         float qr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) qr[e] = qs[kc_ * 8 + e];
         for (int j0 = ksub; j0 < pos; j0 += KPB * UK) {
-            float kk[UK][8];
+            Raw8<T> kr[UK];
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 const int j = j0 + u * KPB;
-                if (j < pos) load8<T>(kbase + (int64_t)j * D + kc_ * 8, kk[u]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) kk[u][e] = 0.f;
-                }
+                if (j < pos) kr[u].load(kbase + (int64_t)j * D + kc_ * 8);
+                else kr[u].zero();
             }
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
+                float kk[8];
+                kr[u].get(kk);
                 float acc = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += qr[e] * kk[u][e];
+                for (int e = 0; e < 8; ++e) acc += qr[e] * kk[e];
 #pragma unroll
                 for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
                 const int j = j0 + u * KPB;
