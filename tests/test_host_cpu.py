@@ -247,3 +247,19 @@ def test_benchmark_input_generator_matches_the_oracle_recipe():
         assert torch.equal(a, b)
     px = make_inputs(visualcla.visualcla_7b_config(), 1, 128, image_size=336)[0]
     assert px.shape == (1, 3, 336, 336)
+
+
+def test_header_is_plain_c_and_a_c_program_links_the_library(tmp_path):
+    """the drop-in boundary is a C ABI: compile a C99 translation unit against include/visualcla_hip.h with warnings as errors,
+    link it to libvisualcla_hip.so and run the entry points that validate arguments before touching a device"""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    from visualcla import _lib
+    exe = str(tmp_path / "c_abi_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_check.c"),
+           "-o", exe, "-L", libdir, "-l:libvisualcla_hip.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi" in r.stdout and "last error:" in r.stdout
