@@ -716,6 +716,9 @@ __global__ __launch_bounds__(1024) void gemm_panel_reduce_norm_kernel(vcla_gemm_
 static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
     const int tiles_n = (a->N + PN_BN - 1) / PN_BN, nk = a->K / GM_BK;
     int s = (320 + tiles_n / 2) / tiles_n;
+    // M > 64 (8 MFMA row tiles): 270 registers per lane = ONE workgroup per CU, so a grid above 256 runs a second round
+    // (measured: 198 -> 173 us per layer for the four M = 128 GEMMs)
+    if (a->M > 64) s = 256 / tiles_n;
     if (s < 1) s = 1;
     if (s > 8) s = 8;
     if (s > nk) s = nk;
