@@ -454,7 +454,7 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
 // the waves (= loads in flight) per CU at the same grid, half the split-K partials for the same number of K streams: the
 // launch can then stay at <= 256 workgroups (one per CU, no second round) and the big-N GEMMs need no partials at all.
 template <int EPI, typename OutT, int MT, int WMODE, int KG = 1>
-__global__ __launch_bounds__(256 * KG) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
+__global__ __launch_bounds__(256 * KG, (MT == 8 && KG == 1) ? 2 : 1) void gemm_panel_kernel(vcla_gemm_args a, int splitk, int n_pad, float* __restrict__ partial) {
     constexpr int NA = (MT * 128 + 255) / 256;  // 16-byte A chunks per thread per K tile
     __shared__ __attribute__((aligned(16))) unsigned char As_all[KG][2][MT * 16 * 128];
     const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
@@ -716,9 +716,9 @@ __global__ __launch_bounds__(1024) void gemm_panel_reduce_norm_kernel(vcla_gemm_
 static int panel_splitk(const vcla_gemm_args* a, int n_pad) {
     const int tiles_n = (a->N + PN_BN - 1) / PN_BN, nk = a->K / GM_BK;
     int s = (320 + tiles_n / 2) / tiles_n;
-    // M > 64 (8 MFMA row tiles): 270 registers per lane = ONE workgroup per CU, so a grid above 256 runs a second round
-    // (measured: 198 -> 173 us per layer for the four M = 128 GEMMs)
-    if (a->M > 64) s = 256 / tiles_n;
+    // M > 64 (8 MFMA row tiles): the kernel is held to 246 registers (launch bounds) = two workgroups per CU; the grid
+    // stays within that one round of 512 (measured: 198 -> 158 us per layer for the four M = 128 GEMMs)
+    if (a->M > 64) s = 512 / tiles_n;
     if (s < 1) s = 1;
     if (s > 8) s = 8;
     if (s > nk) s = nk;
