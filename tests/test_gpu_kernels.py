@@ -565,3 +565,28 @@ def test_gemm_post_norm_is_the_rmsnorm_of_its_own_output(lib, M, N, K, frag):
     assert torch.equal(x, plain)
     with pytest.raises(ValueError):
         lib.gemm(a, wp, N, epilogue=1, post_norm_gamma=gamma, post_norm_eps=1e-6, post_norm_out=h)
+
+
+@pytest.mark.parametrize("M", [2, 33, 64, 100])
+@pytest.mark.parametrize("tag,N,K,epi", [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_panel_gemm_on_the_7b_decode_geometries(lib, M, tag, N, K, epi, fp8):
+    """the exact launch geometries of batch decode at 7B (8-wave two-K-group form for M <= 64: gate/up without split-K, qkv with
+    2 slices, o / down with 8; 4-wave form at M = 100) against an fp32 matmul of the same bf16 (or dequantised fp8) operands"""
+    from visualcla.weights import to_fragment_major, quantize_fp8_rows, dequantize_fp8_rows, to_fragment_pair_major_fp8
+    g = torch.Generator().manual_seed(M * 31 + N // 64 + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    wp = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16, device=DEV)
+    wp[:N] = (torch.randn(N, K, generator=g) * 0.03).to(DEV, torch.bfloat16)
+    n_out = N // 2 if epi == 3 else N
+    res = torch.randn(M, n_out, generator=g).to(DEV, torch.bfloat16)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    if fp8:
+        q8, sc8 = quantize_fp8_rows(wp)
+        w_ref = dequantize_fp8_rows(q8, sc8)[:N]
+        got = lib.gemm(a, wp, N, residual=res, epilogue=epi, splitk_ws=ws, w_q8=q8, w_q8_frag=to_fragment_pair_major_fp8(q8), w_scale=sc8)
+    else:
+        w_ref = wp[:N]
+        got = lib.gemm(a, wp, N, residual=res, epilogue=epi, splitk_ws=ws, w_frag=to_fragment_major(wp))
+    ref = _gemm_ref(a.float().cpu(), w_ref.float().cpu(), None, epi, res.float().cpu())
+    _cmp(f"panel7b[{tag},M{M},fp8={fp8}]", got, ref, atol=2e-2, rtol=1e-2)
