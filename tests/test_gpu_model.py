@@ -312,3 +312,39 @@ def test_set_image_size_retargets_the_vision_tower(golden_dir):
     toks = mb.generate(input_ids=ids2.cuda(), pixel_values=px2.cuda(), attention_mask=mask2.cuda(), max_new_tokens=3, do_sample=False,
                        eos_token_id=None)
     assert toks.shape == (2, 3)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_7b_batch64_decode_matches_full_forward(model_7b, fp8):
+    """configs[2] geometry (B = 64: 8-wave panel GEMMs, row-cooperative decode attention, fused reduce + RMSNorm): every token a
+    decode step picks must be the argmax of the full-sequence forward logits at that position wherever the top-2 margin there is
+    outside bf16 / fp8 noise"""
+    m, ocfg = model_7b
+    B, T, n_new = 64, 128, 4
+    px, ids, mask = O.make_inputs(ocfg, B, T)
+    px, ids, mask = px.cuda(), ids.cuda(), mask.cuda()
+    if fp8:
+        m.enable_fp8_decode()
+    try:
+        toks = m.generate(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=n_new, do_sample=False, eos_token_id=None)
+    finally:
+        if fp8:
+            m.enable_fp8_decode(False)
+    full = m.forward(input_ids=torch.cat([ids, toks[:, :n_new - 1]], 1), pixel_values=px,
+                     attention_mask=torch.ones(B, T + n_new - 1, dtype=torch.int64, device="cuda")).logits
+    assert torch.isfinite(full).all()
+    margin = 0.5 if fp8 else 0.1        # fp8 decode weights vs the bf16 forward: ~3 mantissa bits on the weights
+    checked = agree = 0
+    alive = torch.ones(B, dtype=torch.bool, device="cuda")     # a row is compared until its first undecided position
+    for s in range(n_new):
+        lg = full[:, T - 1 + s].float()
+        top2 = lg.topk(2, dim=-1)
+        decided = ((top2.values[:, 0] - top2.values[:, 1]) > margin) & alive
+        checked += int(decided.sum())
+        agree += int((top2.indices[:, 0] == toks[:, s])[decided].sum())
+        alive &= decided
+    _report(f"7B B=64 fp8={fp8}: {agree}/{checked} decided positions agree with the full forward")
+    if fp8:     # quantisation noise is not bounded by a fixed margin on a random-weight model: ask for near-total agreement
+        assert checked >= 16 and agree >= 0.9 * checked
+    else:
+        assert checked >= B and agree == checked
