@@ -45,7 +45,7 @@ def _cmp(name, got, ref, atol, rtol=0.0):
 
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,cols", [(5, 128), (257, 1024), (33, 4096), (3, 100)])
+@pytest.mark.parametrize("rows,cols", [(5, 128), (257, 1024), (33, 4096), (3, 100), (6, 512), (1030, 1536), (2, 2048)])
 def test_layernorm(lib, dtype, rows, cols):
     g = torch.Generator().manual_seed(rows * 7 + cols)
     x = torch.randn(rows, cols, generator=g) * 2 + 0.3
