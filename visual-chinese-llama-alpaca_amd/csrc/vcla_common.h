@@ -127,8 +127,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(a x) with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions): the activation
+// epilogue of a 256x256 tile is 128 values per lane
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 #endif  // __HIPCC__
