@@ -24,6 +24,7 @@
  *                           models/visualcla/modeling_visualcla.py:284,350;
  *                           models/visualcla/modeling_visual_resampler.py:276,356
  *   vcla_rmsnorm            LlamaRMSNorm.forward hf:llama/modeling_llama.py:62-67
+ *   vcla_rmsnorm_pack       the same, output in the MFMA-fragment-major layout of the batch-decode GEMMs
  *   vcla_gemm               every nn.Linear on the path (hf:clip/modeling_clip.py:280-282,332,345-347;
  *                           modeling_visual_resampler.py:174,187-188,274,341,354;
  *                           modeling_visualcla.py:288,354; hf:llama/modeling_llama.py:175,250-252,280,480)
@@ -55,7 +56,7 @@
 extern "C" {
 #endif
 
-#define VCLA_ABI_VERSION 1
+#define VCLA_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -114,7 +115,9 @@ typedef struct vcla_gemm_args {
     int force_kernel;     /* 0 auto; 1 MFMA 128x128 tile; 2 GEMV (M <= 8); 3 fp32 tile; 4 MFMA 256x256 direct-to-LDS;
                              5 = 4 without the hand-placed ds_read/MFMA interleave; 6 generic GEMV (no LDS x staging);
                              7 skinny MFMA (2 <= M <= 128, W streamed once, intra-workgroup split-K);
-                             8 panel MFMA (M <= 128, activations shared through LDS, split-K over workgroups) */
+                             8 panel MFMA (M <= 128, activations shared through LDS, split-K over workgroups);
+                             9 streaming MFMA (M <= 64, needs A_frag + W_frag / W_q8_frag: every CU streams an equal share of W over
+                               the FULL K, no split-K partials, no LDS in the main loop) */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */
@@ -140,10 +143,24 @@ typedef struct vcla_gemm_args {
     float post_norm_eps;
     void* post_norm_out;
     int64_t post_norm_ld;
+    /* optional fragment-major activations for the streaming decode GEMM (kernel 9): A_frag [K/32][ceil(M/16)][64 lanes][8]
+       act dtype bf16, element (m, k) at ((k/32 * MT + m/16) * 64 + ((k%32)/8)*16 + m%16) * 8 + k%8 -- each MFMA operand
+       fragment is one contiguous 1 KiB block (vcla_rmsnorm_pack, vcla_attn_decode_fused(out_frag) and C_frag produce it).
+       When set (with M <= 64 and W_frag or W_q8_frag) `A` may be NULL. */
+    const void* A_frag;
+    /* optional second output in the same fragment-major layout, [N_out/32][ceil(M/16)][64][8] bf16 (N_out % 32 == 0): feeds the
+       next streaming GEMM (SwiGLU activations -> down_proj).  When set, `C` may be NULL (no row-major copy is stored). */
+    void* C_frag;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */
 int vcla_gemm(const vcla_gemm_args* args, int dtype, void* stream);
+
+/* LlamaRMSNorm (hf:llama/modeling_llama.py:62-67) of `rows` <= 64 bf16 rows, written in the fragment-major layout the
+   streaming decode GEMM reads (vcla_gemm_args.A_frag): y_frag [cols/32][ceil(rows/16)][64][8] bf16; values bit-identical to
+   vcla_rmsnorm.  gamma == NULL: plain re-layout (no normalisation).  cols % 32 == 0. */
+int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma, void* y_frag, int rows, int cols, float eps,
+                      void* stream);
 
 /* Tuning harness (not used by the product path): the M = 1 bf16 GEMV with its streaming knobs exposed.
    variant = rows_per_wave | k_unroll << 8 | x_in_lds << 16 | nontemporal << 17 | waves_per_block << 20. */
@@ -202,10 +219,11 @@ int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* co
 
 /* Fused decode-step attention for every (sequence, head): RoPE on q and the new k of the fused qkv row [B, 3*H*d],
    append k / v to the cache at position pos0 + (pos_dev ? *pos_dev : 0), softmax(scale q K^T) V over keys 0..pos.
-   out [B, H*d].  key_mask [B, key_mask_ld] optional. */
+   out [B, H*d]; out_frag != 0 (bf16 only, B <= 64): out is written in the fragment-major layout of vcla_gemm_args.A_frag
+   ([H*d/32][ceil(B/16)][64][8]) for the streaming o_proj GEMM.  key_mask [B, key_mask_ld] optional. */
 int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
                            void* out, int B, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev,
-                           const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, void* stream);
+                           const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, int out_frag, void* stream);
 
 /* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
 int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);

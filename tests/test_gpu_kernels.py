@@ -398,7 +398,7 @@ def test_attn_decode_fused(lib, dtype, B, H, d, pos):
     L = lib.load()
     lib.check(L.vcla_attn_decode_fused(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(),
                                        out.data_ptr(), B, H, d, ctx, pos - dev_part, pos_dev.data_ptr(), km_d.data_ptr(), ctx,
-                                       1 / math.sqrt(d), lib.dtype_code(dtype), lib.stream_ptr()))
+                                       1 / math.sqrt(d), lib.dtype_code(dtype), 0, lib.stream_ptr()))
     torch.cuda.synchronize()
     _cmp(f"attn_decode_fused[{dtype},B{B}H{H}d{d}pos{pos}]", out.view(B, 1, H * d), ref, atol=3e-5 if dtype == torch.float32 else 1.5e-2)
     # the cache must now hold the roped key / raw value at `pos`, everything else untouched
@@ -590,3 +590,126 @@ def test_panel_gemm_on_the_7b_decode_geometries(lib, M, tag, N, K, epi, fp8):
         got = lib.gemm(a, wp, N, residual=res, epilogue=epi, splitk_ws=ws, w_frag=to_fragment_major(wp))
     ref = _gemm_ref(a.float().cpu(), w_ref.float().cpu(), None, epi, res.float().cpu())
     _cmp(f"panel7b[{tag},M{M},fp8={fp8}]", got, ref, atol=2e-2, rtol=1e-2)
+
+
+# ------------------------------------------------------------------ streaming decode GEMM (kernel 9) and its fragment-major producers
+@pytest.mark.parametrize("rows,cols", [(64, 4096), (2, 256), (33, 512), (17, 8192), (48, 1408)])
+def test_rmsnorm_pack_is_the_rmsnorm_in_fragment_layout(lib, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.5).to(DEV, torch.bfloat16)
+    gamma = (1 + 0.1 * torch.randn(cols, generator=g)).to(DEV)
+    want = lib.rmsnorm(x, gamma, 1e-6)
+    got = lib.rmsnorm_pack(x, gamma, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(lib.from_frag(got, rows), want)                 # bit-identical values, only the layout differs
+    assert torch.equal(got, lib.to_frag(want))                         # padding rows stay zero
+    assert torch.equal(lib.rmsnorm_pack(x, None, 0.0), lib.to_frag(x))  # gamma = NULL: plain re-layout
+
+
+DS_SHAPES = [
+    # M, N, K
+    (64, 4096, 4096), (64, 12288, 4096), (64, 4096, 11008), (2, 512, 256), (33, 1000, 1408), (7, 320, 64), (16, 128, 512),
+    (48, 2080, 2048), (64, 49958, 512), (17, 96, 4096), (3, 16, 8192),
+]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("epi", [0, 3])
+@pytest.mark.parametrize("M,N,K", DS_SHAPES)
+def test_gemm_dstream(lib, M, N, K, epi, fp8):
+    """kernel 9: fragment-major A and W, every workgroup an equal share of tiles over the full K, cross-wave reduction in LDS"""
+    from visualcla.weights import to_fragment_major, quantize_fp8_rows, dequantize_fp8_rows, to_fragment_pair_major_fp8
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M * 1000 + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    wp = _pack(w)
+    kw = dict(w_frag=to_fragment_major(wp))
+    wref = w
+    if fp8:
+        q, sc = quantize_fp8_rows(wp)
+        wref = dequantize_fp8_rows(q, sc)[:N].cpu()
+        kw = dict(w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc)
+    ref = _gemm_ref(a, wref, bias, epi, res)
+    af = lib.to_frag(a.to(DEV, torch.bfloat16))
+    cf = torch.zeros(n_out // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if n_out % 32 == 0 else None
+    got = lib.gemm(None, wp, N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi, force_kernel=9,
+                   a_frag=af, m=M, c_frag=cf, **kw)
+    _cmp(f"gemm_dstream[fp8={fp8},epi{epi},{M}x{N}x{K}]", got, ref, atol=3e-3 if fp8 else 2e-3, rtol=8e-3)
+    if cf is not None:
+        torch.cuda.synchronize()
+        assert torch.equal(lib.from_frag(cf, M), got)                  # the fragment-major copy holds the same bf16 values
+    if epi == 0:   # fp32 output (lm_head), no residual / bias
+        got32 = lib.gemm(None, wp, N, out_f32=True, force_kernel=9, a_frag=af, m=M, **kw)
+        _cmp(f"gemm_dstream_f32[fp8={fp8},{M}x{N}x{K}]", got32, _gemm_ref(a, wref, None, 0, None), atol=1e-3, rtol=2e-3)
+
+
+def test_gemm_dstream_identity_in_place_and_determinism(lib):
+    from visualcla.weights import to_fragment_major
+    # A = I with an asymmetric W catches operand / row-column swaps of either fragment layout
+    M, K, N = 48, 192, 333
+    a = torch.zeros(M, K)
+    a[torch.arange(M), (torch.arange(M) * 3) % K] = 1.0
+    g = torch.Generator().manual_seed(5)
+    w = bf16r(torch.randn(N, K, generator=g))
+    wp = _pack(w)
+    got = lib.gemm(None, wp, N, out_f32=True, force_kernel=9, a_frag=lib.to_frag(a.to(DEV, torch.bfloat16)), m=M, w_frag=to_fragment_major(wp))
+    _cmp("gemm_dstream_identity", got, a @ w.t(), atol=0.0)
+    # residual read and written in place (the decode residual stream), twice the same bits
+    M, N, K = 64, 4096, 4096
+    a, w2, x = bf16r(torch.randn(M, K, generator=g)), bf16r(torch.randn(N, K, generator=g) * 0.05), bf16r(torch.randn(M, N, generator=g))
+    wp2 = _pack(w2)
+    wf2, af = to_fragment_major(wp2), lib.to_frag(a.to(DEV, torch.bfloat16))
+    outs = []
+    for _ in range(2):
+        xd = x.to(DEV, torch.bfloat16)
+        lib.gemm(None, wp2, N, residual=xd, out=xd, force_kernel=9, a_frag=af, m=M, w_frag=wf2)
+        outs.append(xd)
+    _cmp("gemm_dstream_inplace_residual", outs[0], x + a @ w2.t(), atol=2e-3, rtol=8e-3)
+    assert torch.equal(outs[0], outs[1])
+    # and the same function as the panel kernel it replaces, to accumulation-order noise
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    ref8 = lib.gemm(a.to(DEV, torch.bfloat16), wp2, N, out_f32=True, force_kernel=8, splitk_ws=ws, w_frag=wf2)
+    got9 = lib.gemm(None, wp2, N, out_f32=True, force_kernel=9, a_frag=af, m=M, w_frag=wf2)
+    _cmp("gemm_dstream_vs_panel", got9, ref8, atol=2e-4, rtol=1e-4)
+
+
+def test_gemm_dstream_error_conventions(lib):
+    from visualcla.weights import to_fragment_major
+    a = torch.randn(65, 256).to(DEV, torch.bfloat16)
+    wp = _pack(torch.randn(128, 256))
+    with pytest.raises(ValueError):    # M > 64
+        lib.gemm(None, wp, 128, force_kernel=9, a_frag=lib.to_frag(a), m=65, w_frag=to_fragment_major(wp))
+    with pytest.raises(ValueError):    # no fragment-major weights
+        lib.gemm(None, wp, 128, force_kernel=9, a_frag=lib.to_frag(a[:8]), m=8)
+    with pytest.raises(ValueError):    # an activation epilogue the streaming kernel does not implement
+        lib.gemm(None, wp, 128, force_kernel=9, a_frag=lib.to_frag(a[:8]), m=8, w_frag=to_fragment_major(wp), epilogue=1)
+    with pytest.raises(ValueError):    # C_frag from a kernel that cannot write it
+        lib.gemm(a[:8], wp, 128, force_kernel=1, c_frag=torch.zeros(4, 1, 64, 8, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.mark.parametrize("B,H,d,pos", [(64, 32, 128, 190), (2, 4, 128, 37), (33, 8, 64, 3), (16, 32, 32, 65)])
+def test_attn_decode_fragment_major_output(lib, B, H, d, pos):
+    """out_frag = 1 stores the same values as the row-major form, in the layout the streaming o_proj GEMM reads"""
+    from visualcla.weights import rope_tables
+    ctx = max(64, (pos + 64) // 64 * 64)
+    g = torch.Generator().manual_seed(B + H + d + pos)
+    qkv = torch.randn(B, 3 * H * d, generator=g).to(DEV, torch.bfloat16)
+    kc0 = torch.randn(B, H, ctx, d, generator=g).to(DEV, torch.bfloat16)
+    vc0 = torch.randn(B, H, ctx, d, generator=g).to(DEV, torch.bfloat16)
+    cos, sin = (t.to(DEV) for t in rope_tables(1024, d, 10000.0))
+    outs = []
+    for frag in (0, 1):
+        kc, vc = kc0.clone(), vc0.clone()
+        out = torch.zeros((H * d) // 32, (B + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if frag else \
+            torch.empty(B, H * d, dtype=torch.bfloat16, device=DEV)
+        lib.check(lib.load().vcla_attn_decode_fused(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                    out.data_ptr(), B, H, d, ctx, pos, None, None, 0, 1 / math.sqrt(d),
+                                                    lib.dtype_code(torch.bfloat16), frag, lib.stream_ptr()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(lib.from_frag(outs[1], B), outs[0])

@@ -182,8 +182,60 @@ def main():
                     t = timeit(run, reps=10) / 4
                     print(f"k{fk}{'f' if frag else ' '} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
                 del ws, wfs
+    if "dstream" in which:
+        # batch-decode GEMMs: split-K panel kernel (8, + its reduce launches) vs the streaming kernel (9), bf16 and fp8 weights,
+        # rotating over 4 weight buffers so the figures are HBM figures
+        from visualcla.weights import to_fragment_major, quantize_fp8_rows, to_fragment_pair_major_fp8
+        print("== batch-decode GEMMs: panel split-K (k8) vs streaming (k9); env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_")))
+        skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        for M in [int(x) for x in os.environ.get("VCLA_BENCH_MS", "64,32,16").split(",")]:
+            tot = {"k8": 0.0, "k9": 0.0, "k8q": 0.0, "k9q": 0.0}
+            for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0),
+                                   ("lm_head", 49958, 4096, 0)):
+                n_out = N // 2 if epi == 3 else N
+                a = rnd(M, K)
+                af = _lib.to_frag(a)
+                nb = 2 if tag == "lm_head" else 4
+                ws = [packw(N, K) for _ in range(nb)]
+                wfs = [to_fragment_major(w) for w in ws]
+                out = torch.empty(M, n_out, dtype=torch.float32 if tag == "lm_head" else torch.bfloat16, device=DEV)
+                res = rnd(M, n_out) if tag in ("o", "down") else None
+                gam = torch.ones(n_out, device=DEV)
+                hn = torch.empty(M, n_out, dtype=torch.bfloat16, device=DEV)
+                f32 = tag == "lm_head"
+                def run8():
+                    for w, wf in zip(ws, wfs):
+                        if res is not None:    # as the engine runs it: fused reduce + next RMSNorm
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, residual=res, force_kernel=8, splitk_ws=skws, w_frag=wf, post_norm_gamma=gam, post_norm_eps=1e-6, post_norm_out=hn)
+                        else:
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, out_f32=f32, force_kernel=8, splitk_ws=skws, w_frag=wf)
+                def run9():
+                    for w, wf in zip(ws, wfs):
+                        _lib.gemm(None, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, force_kernel=9, a_frag=af, m=M, w_frag=wf)
+                t8, t9 = timeit(run8, reps=10) / nb, timeit(run9, reps=10) / nb
+                qs = [quantize_fp8_rows(w) for w in ws]
+                qfs = [to_fragment_pair_major_fp8(q) for q, _ in qs]
+                def run8q():
+                    for w, (q, sc), qf in zip(ws, qs, qfs):
+                        _lib.gemm(a, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, force_kernel=8, splitk_ws=skws, w_q8=q, w_q8_frag=qf, w_scale=sc)
+                def run9q():
+                    for w, (q, sc), qf in zip(ws, qs, qfs):
+                        _lib.gemm(None, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, force_kernel=9, a_frag=af, m=M, w_q8_frag=qf, w_scale=sc)
+                t8q, t9q = timeit(run8q, reps=10) / nb, timeit(run9q, reps=10) / nb
+                by = ws[0].shape[0] * K * 2
+                print(f"M={M:3d} {tag:8s} N={N:6d} K={K:6d}  k8 {t8*1e6:7.1f} us {by/t8/1e9:6.0f} GB/s | k9 {t9*1e6:7.1f} us {by/t9/1e9:6.0f} GB/s"
+                      f" || fp8: k8 {t8q*1e6:7.1f} us {by/2/t8q/1e9:6.0f} GB/s | k9 {t9q*1e6:7.1f} us {by/2/t9q/1e9:6.0f} GB/s")
+                if tag != "lm_head":
+                    for k_, t_ in (("k8", t8), ("k9", t9), ("k8q", t8q), ("k9q", t9q)):
+                        tot[k_] += t_
+                del ws, wfs, qs, qfs
+            xn = rnd(M, 4096)
+            gam = torch.ones(4096, device=DEV)
+            pk = _lib.rmsnorm_pack(xn, gam, 1e-6)
+            tp = timeit(lambda: _lib.rmsnorm_pack(xn, gam, 1e-6, out=pk), reps=50)
+            print(f"M={M:3d} layer GEMMs: k8 (incl. reduce+norm launches) {tot['k8']*1e6:.1f} us | k9 {tot['k9']*1e6:.1f} us + 2 x rmsnorm_pack {tp*1e6:.1f} us"
+                  f" = {(tot['k9'] + 2 * tp)*1e6:.1f} us ({404e6/(tot['k9'] + 2 * tp)/1e9:.0f} GB/s over 404 MB) || fp8: k8 {tot['k8q']*1e6:.1f} | k9 {tot['k9q']*1e6:.1f} us")
     if "panel" in which:
-        import os
         print(f"== panel split-K kernel (fragment-major W), M=64, env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_PANEL")))
         skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
         from visualcla.weights import to_fragment_major
@@ -217,7 +269,6 @@ def main():
                 del ws, wfs, qs, qfs
         print(f"layer total {tot*1e6:.1f} us  ({404e6/tot/1e9:.0f} GB/s over the 404 MB of layer weights); fp8 copies: {tot8*1e6:.1f} us")
     if "gemv1" in which:
-        import os
         print("== M=1 GEMV on the decode shapes, rotating over 8 weight buffers (HBM-resident); env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_GEMV1")))
         tot = 0.0
         for tag, N, K, epi, fused in (("qkv", 12288, 4096, 0, True), ("o", 4096, 4096, 0, False), ("gate-up", 22016, 4096, 3, True), ("down", 4096, 11008, 0, False)):

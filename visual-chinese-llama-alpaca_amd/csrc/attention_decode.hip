@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
                                                           const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                           T* __restrict__ out, int H, int ctx_max, int pos0,
                                                           const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
-                                                          int64_t key_mask_ld, float scale, int sc_cap) {
+                                                          int64_t key_mask_ld, float scale, int sc_cap, int out_frag_mt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qs = smem;              // [D]   roped query
     float* knew = smem + D;        // [D]   roped new key
@@ -244,25 +244,35 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         for (int e = 0; e < 8; ++e) part[wave * D + lane * 8 + e] = o[e];
     }
     __syncthreads();
-    if (tid < D) Act<T>::st(out + (int64_t)b * HD + h * D + tid, part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]);
+    if (tid < D) {
+        const float o_ = part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid];
+        if (out_frag_mt > 0) {
+            // fragment-major store for the streaming o_proj GEMM (vcla_gemm_args.A_frag): row b, column k = h*D + tid
+            const int k = h * D + tid;
+            Act<T>::st(out + ((((int64_t)(k >> 5) * out_frag_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7), o_);
+        } else {
+            Act<T>::st(out + (int64_t)b * HD + h * D + tid, o_);
+        }
+    }
 }
 
 template <typename T, int D>
 static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_tab, const float* sin_tab, void* out, int B,
                          int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
-                         float scale, hipStream_t s) {
+                         float scale, int out_frag, hipStream_t s) {
     const int sc_cap = (ctx_max + 63) & ~63;
     const size_t lds = (size_t)(3 * D + 8 + 4 * D + sc_cap) * sizeof(float);
     VCLA_REQUIRE(lds <= 64 * 1024, VCLA_ERR_BAD_SHAPE, "attn_decode: ctx_max=%d needs %zu B of LDS (max 64 KiB)", ctx_max, lds);
     dim3 grid(H, B);
+    const int out_frag_mt = out_frag ? (B + 15) / 16 : 0;
     static const int coop_env = getenv("VCLA_ATTN_COOP") ? atoi(getenv("VCLA_ATTN_COOP")) : -1;   // -1 auto, 0 / 1 force (A/B runs)
     const bool coop = coop_env >= 0 ? coop_env != 0 : (int64_t)B * H >= 512;
     if (coop)
         attn_decode_kernel<T, D, true><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
-                                                              pos_dev, key_mask, key_mask_ld, scale, sc_cap);
+                                                              pos_dev, key_mask, key_mask_ld, scale, sc_cap, out_frag_mt);
     else
         attn_decode_kernel<T, D, false><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
-                                                               pos_dev, key_mask, key_mask_ld, scale, sc_cap);
+                                                               pos_dev, key_mask, key_mask_ld, scale, sc_cap, out_frag_mt);
     VCLA_CHECK_LAUNCH("attn_decode_kernel");
     return VCLA_OK;
 }
@@ -270,7 +280,7 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
 extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
                                       const float* sin_tab, void* out, int B, int H, int d, int ctx_max, int pos0,
                                       const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
-                                      int dtype, void* stream) {
+                                      int dtype, int out_frag, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode: bad dtype %d", dtype);
     VCLA_REQUIRE(d == 32 || d == 64 || d == 128, VCLA_ERR_BAD_SHAPE, "attn_decode: head dim %d not in {32,64,128}", d);
     VCLA_REQUIRE(B >= 0 && H > 0 && ctx_max > 0 && pos0 >= 0 && (pos_dev || pos0 < ctx_max), VCLA_ERR_BAD_SHAPE,
@@ -278,9 +288,11 @@ extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_ca
     VCLA_REQUIRE(qkv && k_cache && v_cache && cos_tab && sin_tab && out, VCLA_ERR_BAD_ARG, "attn_decode: null pointer");
     VCLA_REQUIRE(vcla_aligned(k_cache, 16) && vcla_aligned(v_cache, 16) && vcla_aligned(qkv, 16), VCLA_ERR_BAD_ARG,
                  "attn_decode: buffers must be 16-byte aligned");
+    VCLA_REQUIRE(!out_frag || (dtype == VCLA_BF16 && B <= 64 && (H * d) % 32 == 0), VCLA_ERR_BAD_ARG,
+                 "attn_decode: out_frag needs bf16, B <= 64 (got %d) and H*d %% 32 == 0", B);
     if (B == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
-#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, s)
+#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag, s)
     if (dtype == VCLA_F32) {
         if (d == 32) DEC_CASE(float, 32);
         if (d == 64) DEC_CASE(float, 64);

@@ -9,6 +9,7 @@
 // Memory: nothing is allocated here.  Weights are caller-owned device tensors registered by name; activations
 // live in a caller-provided workspace carved by a bump allocator; the KV cache is caller-owned.
 #include "vcla_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -348,7 +349,7 @@ struct LlamaWs {
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
     const size_t e = esz(ctx);
-    const size_t M = (size_t)B * T;
+    const size_t M = ((size_t)B * T + 15) / 16 * 16;   // rows padded to whole 16-row MFMA tiles (fragment-major decode buffers)
     Bump b{base, 0, 0};
     LlamaWs t;
     t.x = b.take(M * c.t_hidden * e);
@@ -397,6 +398,17 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
         else a.W_frag = wv->frag;
     }
     return vcla_gemm(&a, ctx->c.act_dtype, s);
+}
+
+// streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
+static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
+                   void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0) {
+    vcla_gemm_args a{};
+    a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
+    a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
+    if (g_decode_step && wv.q8f && wv.s8) { a.W_q8_frag = wv.q8f; a.w_scale = wv.s8; }
+    else a.W_frag = wv.frag;
+    return vcla_gemm(&a, VCLA_BF16, s);
 }
 
 #define RUN(expr)            \
@@ -501,6 +513,23 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     const size_t per = (size_t)B * H * ctx_max * d * e;  // bytes of one K (or V) slab of one layer
     char* kc = (char*)kv_cache + (size_t)(2 * l) * per;
     char* vc = kc + per;
+    // 2 <= M <= 64 decode rows with fragment-major weight copies: the streaming GEMMs (gemm_stream.hip).  Every operand is
+    // fragment-major: RMSNorm writes its output that way (vcla_rmsnorm_pack), the attention kernel stores its output that way,
+    // the SwiGLU epilogue stores the activations that way; the residual stream w.x stays row-major.  7 launches per layer,
+    // no split-K partials.
+    static const int ds_env = getenv("VCLA_DSTREAM") ? atoi(getenv("VCLA_DSTREAM")) : 1;
+    const bool has_frag = (L.vqkv.frag && L.vo.frag && L.vgu.frag && L.vd.frag) || (L.vqkv.q8f && L.vo.q8f && L.vgu.q8f && L.vd.q8f);
+    if (ds_env && T == 1 && dt == VCLA_BF16 && M >= 2 && M <= 64 && has_frag && D % 32 == 0 && c.t_inter % 32 == 0) {
+        RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
+        RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE));
+        RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
+                                   1.0f / sqrtf((float)d), dt, /*out_frag=*/1, s));
+        RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, nullptr, M, D, D, VCLA_EPI_NONE));
+        RUN(vcla_rmsnorm_pack(w.x, D, L.ln2g, w.h, M, D, c.t_eps, s));
+        RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+        RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, nullptr, M, D, c.t_inter, VCLA_EPI_NONE));
+        return VCLA_OK;
+    }
     // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
     const bool fused = (dt == VCLA_F32) ? (M <= 8) : (M == 1);  // must mirror vcla_gemm's kernel choice
     // Otherwise the norms ride on the producing GEMM (post_norm_*: fused into the split-K reduction for M <= 128, a plain
@@ -516,7 +545,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     if (T == 1) {
         // decode: RoPE + KV append + attention over the cache in one launch
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask,
-                                   ctx_max, scale, dt, s));
+                                   ctx_max, scale, dt, 0, s));
     } else {
         RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dt, s));
         vcla_attn_args a{};
@@ -592,7 +621,18 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
                         l + 1 < c.t_layers ? ctx->llama[l + 1].ln1g : ctx->norm_g));
     float* lg = logits ? logits : w.logits;
-    if ((dt == VCLA_F32) ? (B <= 8) : (B == 1)) {
+    static const int ds_env = getenv("VCLA_DSTREAM") ? atoi(getenv("VCLA_DSTREAM")) : 1;
+    const LlamaLayer& L0 = ctx->llama[0];
+    const bool ds_layers = ds_env && dt == VCLA_BF16 && B >= 2 && B <= 64 && D % 32 == 0 && c.t_inter % 32 == 0 &&
+                           ((L0.vqkv.frag && L0.vo.frag && L0.vgu.frag && L0.vd.frag) || (L0.vqkv.q8f && L0.vo.q8f && L0.vgu.q8f && L0.vd.q8f));
+    if (ds_layers && (ctx->vlm.frag || ctx->vlm.q8f)) {
+        // streaming layers leave the residual stream in w.x: final norm -> fragment-major, lm_head streamed the same way
+        RUN(vcla_rmsnorm_pack(w.x, D, ctx->norm_g, w.h, B, D, c.t_eps, s));
+        RUN(gemm_ds(ctx, s, w.h, ctx->lm_head, ctx->vlm, nullptr, 0, lg, c.t_vocab, nullptr, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+    } else if (ds_layers) {
+        RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, B, D, c.t_eps, dt, s));
+        RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
+    } else if ((dt == VCLA_F32) ? (B <= 8) : (B == 1)) {
         RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps, &ctx->vlm));
     } else {
         RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));

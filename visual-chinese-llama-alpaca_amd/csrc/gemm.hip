@@ -14,85 +14,10 @@
 //                      non-temporal loads, 4 rows per wave, wave-shuffle reduction.  HBM-bound by design.
 //   gemm_f32_kernel    fp32 activations (parity mode): classic 64x64x16 LDS-tiled FMA kernel.
 #include "vcla_common.h"
+#include "gemm_epilogue.h"
 #include <stdlib.h>
 
-// ------------------------------------------------------------------ shared epilogue math
-template <int EPI> __device__ __forceinline__ float epi_act(float x) {
-    if (EPI == VCLA_EPI_QUICK_GELU) return act_quick_gelu(x);
-    if (EPI == VCLA_EPI_GELU_ERF) return act_gelu_erf(x);
-    return x;
-}
-
-__device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
-    if (a.c_group_rows <= 0) return m;
-    return (int64_t)(m / a.c_group_rows) * a.c_group_stride + (m % a.c_group_rows) + a.c_row_offset;
-}
-
-// ---- shared MFMA epilogue.  The wave owns MI x 4 accumulator tiles of 16x16 (operands swapped, see header):
-// acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
-// columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
-template <int EPI, typename OutT, int MI, int NJ = 4>
-__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane) {
-    const int mrow = lane & 15, nq = (lane >> 4) * 4;
-    OutT* Cg = (OutT*)a.C;
-    constexpr bool kF32 = sizeof(OutT) == 4;
-    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
-    const bool vec_c = (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
-    const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mw + i * 16 + mrow;
-        if (m >= a.M) continue;
-        const int64_t crow = remap_row(a, m);
-#pragma unroll
-        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? NJ / 2 : NJ); ++j) {
-            float v[4];
-            int n;  // first output column of this lane's 4
-            if constexpr (EPI == VCLA_EPI_SWIGLU) {
-                n = nw / 2 + j * 16 + nq;
-                const int np_ = nw + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
-                    if (a.w_scale) { gt *= a.w_scale[np_ + r]; up *= a.w_scale[np_ + 16 + r]; }
-                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
-                    v[r] = act_silu(gt) * up;
-                }
-            } else {
-                n = nw + j * 16 + nq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r];
-                    if (a.w_scale) x *= a.w_scale[n + r];   // n + r < N_pad always
-                    if (a.bias && n + r < a.N) x += a.bias[n + r];
-                    v[r] = epi_act<EPI>(x);
-                }
-            }
-            if (n >= n_out) continue;
-            if (a.residual) {
-                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
-                if (vec_r && n + 3 < n_out) {
-                    float rv[4];
-                    Act<bf16_t>::ld4(rp, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < n_out) v[r] += bf2f(rp[r]);
-                }
-            }
-            OutT* cp = Cg + crow * a.ldc + n;
-            if (vec_c && n + 3 < n_out) {
-                Act<OutT>::st4(cp, v);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out) Act<OutT>::st(cp + r, v[r]);
-            }
-        }
-    }
-}
+int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s);   // gemm_stream.hip (kernel 9)
 
 // XCD-aware tile order shared by both MFMA kernels: block b runs on XCD b % 8, so give each XCD a contiguous run of
 // tiles (bijective for any block count), then sweep N inside groups of GRP m-tiles so A panels stay L2-resident.
@@ -1335,6 +1260,8 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
         return a->out_f32 ? launch_skinny<EPI, float>(a, s) : launch_skinny<EPI, bf16_t>(a, s);
     } else if (kernel == 8) {
         return a->out_f32 ? launch_panel<EPI, float>(a, s) : launch_panel<EPI, bf16_t>(a, s);
+    } else if (kernel == 9) {
+        return vcla_gemm_dstream_launch(a, s);
     } else if (kernel == 2 || kernel == 6) {
         if (kernel == 2 && gemv1_applicable(a, dtype)) return launch_gemv1_auto(a, s);
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
@@ -1366,16 +1293,18 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
     VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
-    VCLA_REQUIRE(a->A && a->W && a->C, VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE((a->A || a->A_frag) && a->W && (a->C || a->C_frag), VCLA_ERR_BAD_ARG, "gemm: null pointer");
     VCLA_REQUIRE(a->epilogue >= VCLA_EPI_NONE && a->epilogue <= VCLA_EPI_SWIGLU, VCLA_ERR_BAD_ARG, "gemm: bad epilogue %d",
                  a->epilogue);
     VCLA_REQUIRE(a->epilogue != VCLA_EPI_SWIGLU || a->N % 32 == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: SWIGLU needs N %% 32 == 0 (got %d)", a->N);
     const int64_t aa = dtype == VCLA_F32 ? 4 : 8;
-    VCLA_REQUIRE(a->lda % aa == 0 && a->lda >= a->K && vcla_aligned(a->A, 16) && vcla_aligned(a->W, 16), VCLA_ERR_BAD_SHAPE,
-                 "gemm: A/W must be 16-byte aligned with lda %% %lld == 0 (lda=%lld)", (long long)aa, (long long)a->lda);
+    VCLA_REQUIRE(!a->A || (a->lda % aa == 0 && a->lda >= a->K && vcla_aligned(a->A, 16)), VCLA_ERR_BAD_SHAPE,
+                 "gemm: A must be 16-byte aligned with lda %% %lld == 0 (lda=%lld)", (long long)aa, (long long)a->lda);
+    VCLA_REQUIRE(vcla_aligned(a->W, 16), VCLA_ERR_BAD_SHAPE, "gemm: W must be 16-byte aligned");
     if (a->M == 0) return VCLA_OK;
     int kernel = a->force_kernel;
+    if (kernel == 0 && a->A_frag) kernel = 9;   // fragment-major activations exist only for the streaming decode GEMM
     if (kernel == 0) {
         if (dtype == VCLA_F32) kernel = a->M <= 8 ? 2 : 3;
         else if (a->M == 1 || (a->norm_gamma && a->M <= 8)) kernel = 2;   // GEMV (fused-norm capable)
@@ -1407,7 +1336,17 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             kernel = prefer_256(a) ? 4 : 1;
         }
     }
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 8, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 9, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    if (kernel == 9) {
+        VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_frag && vcla_aligned(a->A_frag, 16) && a->M <= 64 && (a->W_frag || a->W_q8_frag), VCLA_ERR_BAD_ARG,
+                     "gemm: the streaming kernel needs bf16, A_frag, M <= 64 (got %d) and W_frag or W_q8_frag", a->M);
+        VCLA_REQUIRE((a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && a->c_group_rows <= 0 && !a->norm_gamma &&
+                         !a->post_norm_gamma, VCLA_ERR_BAD_ARG, "gemm: the streaming kernel implements epilogues NONE / SWIGLU, no row regrouping, no fused norms");
+        VCLA_REQUIRE(!a->C_frag || (!a->out_f32 && ((a->epilogue == VCLA_EPI_SWIGLU ? a->N / 2 : a->N) % 32 == 0) && vcla_aligned(a->C_frag, 16)),
+                     VCLA_ERR_BAD_ARG, "gemm: C_frag needs a bf16 output whose width is a multiple of 32");
+    } else {
+        VCLA_REQUIRE(a->A && a->C && !a->C_frag, VCLA_ERR_BAD_ARG, "gemm: A_frag / C_frag are implemented by the streaming kernel (9) only");
+    }
     VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
     VCLA_REQUIRE(!((kernel == 2 || kernel == 6) && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
@@ -1418,7 +1357,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights need w_scale and bf16 activations");
     VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
-    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8, VCLA_ERR_BAD_ARG,
+    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9, VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8) and the M <= 128 panel kernel (needs W_q8_frag)");
     VCLA_REQUIRE(!(kernel == 2 && a->w_scale) || (a->W_q8 && gemv1_applicable(a, dtype)), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 GEMV needs W_q8, M = 1, bf16, epilogue NONE/SWIGLU");

@@ -1,0 +1,90 @@
+// gemm_epilogue.h -- epilogue shared by every MFMA GEMM kernel of libvisualcla_hip.so (gemm.hip, gemm_stream.hip).
+#pragma once
+#include "vcla_common.h"
+
+// ------------------------------------------------------------------ shared epilogue math
+template <int EPI> __device__ __forceinline__ float epi_act(float x) {
+    if (EPI == VCLA_EPI_QUICK_GELU) return act_quick_gelu(x);
+    if (EPI == VCLA_EPI_GELU_ERF) return act_gelu_erf(x);
+    return x;
+}
+
+__device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
+    if (a.c_group_rows <= 0) return m;
+    return (int64_t)(m / a.c_group_rows) * a.c_group_stride + (m % a.c_group_rows) + a.c_row_offset;
+}
+
+// ---- shared MFMA epilogue.  The wave owns MI x 4 accumulator tiles of 16x16 (operands swapped, see header):
+// acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
+// columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
+template <int EPI, typename OutT, int MI, int NJ = 4>
+__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane) {
+    const int mrow = lane & 15, nq = (lane >> 4) * 4;
+    OutT* Cg = (OutT*)a.C;
+    constexpr bool kF32 = sizeof(OutT) == 4;
+    const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
+    const bool vec_c = Cg && (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
+    const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 16 + mrow;
+        if (m >= a.M) continue;
+        const int64_t crow = remap_row(a, m);
+#pragma unroll
+        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? NJ / 2 : NJ); ++j) {
+            float v[4];
+            int n;  // first output column of this lane's 4
+            if constexpr (EPI == VCLA_EPI_SWIGLU) {
+                n = nw / 2 + j * 16 + nq;
+                const int np_ = nw + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
+                    if (a.w_scale) { gt *= a.w_scale[np_ + r]; up *= a.w_scale[np_ + 16 + r]; }
+                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
+                    v[r] = act_silu(gt) * up;
+                }
+            } else {
+                n = nw + j * 16 + nq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r];
+                    if (a.w_scale) x *= a.w_scale[n + r];   // n + r < N_pad always
+                    if (a.bias && n + r < a.N) x += a.bias[n + r];
+                    v[r] = epi_act<EPI>(x);
+                }
+            }
+            if (n >= n_out) continue;
+            if (a.residual) {
+                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
+                if (vec_r && n + 3 < n_out) {
+                    float rv[4];
+                    Act<bf16_t>::ld4(rp, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < n_out) v[r] += bf2f(rp[r]);
+                }
+            }
+            if (a.C_frag) {
+                // fragment-major copy for the next streaming GEMM (its K index = this output column n): the lane's 4
+                // consecutive columns are half of one 8-element operand fragment -> one 8-byte store (n_out % 32 == 0)
+                const int mt_c = (a.M + 15) >> 4;
+                bf16_t* fp = (bf16_t*)a.C_frag + ((((int64_t)(n >> 5) * mt_c + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7);
+                *reinterpret_cast<uint2*>(fp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+            if (!Cg) continue;
+            OutT* cp = Cg + crow * a.ldc + n;
+            if (vec_c && n + 3 < n_out) {
+                Act<OutT>::st4(cp, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out) Act<OutT>::st(cp + r, v[r]);
+            }
+        }
+    }
+}
+

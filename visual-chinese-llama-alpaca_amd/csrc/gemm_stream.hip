@@ -1,0 +1,233 @@
+// gemm_stream.hip -- the batch-decode GEMM (2 <= M <= 64 rows): C = epilogue(A . W^T) with W streamed from HBM exactly once.
+//
+// Why a separate kernel.  At M <= 64 every LLaMA projection is a pure weight stream (13.4 GB per decode step shared by the whole
+// batch) and one CU can pull only ~11 B/clk from HBM (MI355X_MICROARCH.md: ~10 B/cyc/CU), so the stream reaches the chip's
+// ~6 TB/s only when ALL 256 CUs pull an EQUAL share for the WHOLE launch.  The split-K panel kernel (gemm.hip, kernel 8) ran the
+// gate/up GEMM on 172 workgroups (22016 / 128 column tiles: a third of the chip idle, 4.4 TB/s) and paid an fp32 partial round
+// trip + a second launch for o_proj / down_proj (profiles/r01_bench_b64_kernel_stats.csv: 8 % of the step).  Here:
+//   * grid = 256 workgroups (one per CU), workgroup g owns the 16-column weight tiles [g*T/256, (g+1)*T/256) over the FULL K:
+//     equal bytes per CU (within one tile), no split-K partials, bias / SwiGLU / residual applied in the launch;
+//   * BOTH operands arrive in MFMA-fragment-major order (W_frag / W_q8_frag packed at load; A_frag written by the producer:
+//     vcla_rmsnorm_pack, vcla_attn_decode_fused(out_frag), or the C_frag epilogue of the previous GEMM), so every operand fetch
+//     is ONE contiguous 1 KiB wave load straight into MFMA registers: no LDS, no barrier in the K loop.  The fetches are buffer
+//     loads (uniform descriptor + one per-lane offset register + a scalar byte offset per load): the address arithmetic of the
+//     whole K loop runs on the scalar unit and the vector registers hold nothing but the operand ring and the accumulators;
+//   * the 8 waves of a workgroup interleave the K stages (wave w takes stages w, w+8, ...), each with its own register ring of
+//     D stages in flight; the hot loop is branch-free (the tile count is a template parameter, the K tail is peeled) so the
+//     compiler emits counted vmcnt waits; the partial tiles meet once, through LDS, after the stream (fixed summation order).
+// The activations (M x K bf16 <= 1.4 MB) are re-read by every workgroup from L2; that traffic (134 MB for K = 4096) rides under
+// the HBM stream (L2 ~34 TB/s).  Algorithmic bytes per launch = N_pad * K * 2 (bf16) or N_pad * K (fp8).
+#include "vcla_common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+
+#define DS_WAVES 8
+#define DS_ROUND 8   // epilogue units reduced per LDS round (one per wave)
+
+// 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
+__device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    const u32x4_t p = {pack_bf2(a.x, a.y), pack_bf2(b.x, b.y), pack_bf2(c.x, c.y), pack_bf2(d.x, d.y)};
+    return __builtin_bit_cast(bf16x8_t, p);
+}
+
+// ring depth: as many stages in flight as fit a ~200-register budget next to the accumulators (acc = NT*MT*4 registers,
+// a stage = (KS*MT + NT)*4), a power of two where possible (K / 256 stages per wave is a power of two for K = 4096: the peeled
+// tail then issues no loads), at most 8
+constexpr int ds_depth(int MT, int NT, bool FP8) {
+    const int acc = NT * MT * 4, st = ((FP8 ? 2 : 1) * MT + NT) * 4;
+    const int d = ((FP8 ? 176 : 200) - acc) / st;   // fp8: the in-register conversion needs temporaries
+    return d >= 8 ? 8 : (d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1)));
+}
+
+struct DsCtx {
+    __amdgpu_buffer_rsrc_t rA, rW;
+    unsigned voff;            // lane * 16
+    unsigned a_stage_bytes;   // A fragments of one stage: KS k-steps x MT tiles x 1 KiB
+    unsigned w_tile_bytes;    // one 16-row weight tile over the full K
+    int wave, lane, nst, mt_c;
+};
+
+// One chunk of NT weight tiles [c0, c0 + NT) x all rows, K stages wave, wave + 8, ... of this wave; then the cross-wave reduction
+// and the epilogue.  MT = 16-row tiles of A; FP8: W_q8_frag (two k-steps per 16-byte lane load) instead of W_frag.
+template <int EPI, typename OutT, int MT, int NT, bool FP8>
+__device__ __forceinline__ void ds_chunk(const vcla_gemm_args& a, const DsCtx& c, int c0, f32x4_t* slab) {
+    constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;       // tiles per epilogue unit (SwiGLU: gate tile + up tile)
+    constexpr int KS = FP8 ? 2 : 1;
+    constexpr int D = ds_depth(MT, NT, FP8);
+    static_assert(NT % TPU == 0, "SwiGLU chunks hold whole gate/up pairs");
+    f32x4_t acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    u32x4_t ra[D][KS][MT], rw[D][NT];
+    const unsigned w_chunk_off = (unsigned)c0 * c.w_tile_bytes;
+    const int T = c.nst;
+
+    // stage t of this wave = global stage ks = wave + 8 t
+#define DS_LOAD(s_, t_)                                                                                         \
+    {                                                                                                           \
+        const unsigned ks_ = (unsigned)(c.wave + DS_WAVES * (t_));                                              \
+        const unsigned ao_ = ks_ * c.a_stage_bytes, wo_ = w_chunk_off + (ks_ << 10);                            \
+        _Pragma("unroll") for (int q = 0; q < KS; ++q)                                                          \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
+                ra[s_][q][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(c.rA, c.voff, ao_ + ((q * c.mt_c + i) << 10), 0)); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                          \
+            rw[s_][j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(c.rW, c.voff, wo_ + j * c.w_tile_bytes, 2 /* nt */)); \
+    }
+#define DS_COMPUTE(s_)                                                                                          \
+    {                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < KS; ++q)                                                          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                    \
+                const bf16x8_t wf_ = FP8 ? (q == 0 ? ds_fp8x8_to_bf16x8(rw[s_][j].x, rw[s_][j].y)                \
+                                                   : ds_fp8x8_to_bf16x8(rw[s_][j].z, rw[s_][j].w))              \
+                                         : __builtin_bit_cast(bf16x8_t, rw[s_][j]);                             \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                  \
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, __builtin_bit_cast(bf16x8_t, ra[s_][q][i]), acc[j][i], 0, 0, 0); \
+            }                                                                                                   \
+    }
+    if (T >= D) {
+        // prologue: D stages in flight before the first MFMA
+#pragma unroll
+        for (int s = 0; s < D; ++s) DS_LOAD(s, s)
+        // steady state: every stage of the ring is computed and refilled; branch-free -> counted vmcnt waits
+        int t0 = 0;
+        for (; t0 + 2 * D <= T; t0 += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                DS_COMPUTE(s)
+                DS_LOAD(s, t0 + s + D)
+            }
+        }
+        // peeled tail: T - t0 in [D, 2D) stages left, the first D of them already in the ring
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            DS_COMPUTE(s)
+            if (t0 + s + D < T) DS_LOAD(s, t0 + s + D)
+        }
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (t0 + D + s < T) DS_COMPUTE(s)
+    } else {
+        // short K (< 256 * D; no LLaMA shape): one stage at a time
+        for (int t = 0; t < T; ++t) {
+            DS_LOAD(0, t)
+            DS_COMPUTE(0)
+        }
+    }
+#undef DS_LOAD
+#undef DS_COMPUTE
+
+    // ---- the 8 K-interleaved partial tiles meet in LDS; wave w reduces and finishes epilogue unit (round base + w).
+    // unit u of the chunk = (tile group jj = u / MT, row tile i = u % MT); SwiGLU units carry the gate and the up tile.
+    constexpr int NU = (NT / TPU) * MT;
+#pragma unroll
+    for (int r0 = 0; r0 < NU; r0 += DS_ROUND) {
+#pragma unroll
+        for (int uu = 0; uu < DS_ROUND; ++uu) {
+            if (r0 + uu < NU) {   // compile-time after unrolling: the accumulator indices below are literals
+                const int u = r0 + uu;
+#pragma unroll
+                for (int tt = 0; tt < TPU; ++tt) slab[((c.wave * DS_ROUND + uu) * TPU + tt) * 64 + c.lane] = acc[(u / MT) * TPU + tt][u % MT];
+            }
+        }
+        __syncthreads();
+        const int u = r0 + c.wave;
+        if (u < NU) {
+            f32x4_t sum[1][TPU];
+#pragma unroll
+            for (int tt = 0; tt < TPU; ++tt) sum[0][tt] = slab[((0 * DS_ROUND + c.wave) * TPU + tt) * 64 + c.lane];
+#pragma unroll
+            for (int w2 = 1; w2 < DS_WAVES; ++w2)
+#pragma unroll
+                for (int tt = 0; tt < TPU; ++tt) {
+                    const f32x4_t p = slab[((w2 * DS_ROUND + c.wave) * TPU + tt) * 64 + c.lane];
+                    sum[0][tt][0] += p[0]; sum[0][tt][1] += p[1]; sum[0][tt][2] += p[2]; sum[0][tt][3] += p[3];
+                }
+            const int jj = u / MT, i = u - jj * MT;
+            gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, c.lane);
+        }
+        __syncthreads();
+    }
+}
+
+// A workgroup walks its share of tiles in chunks of at most 4 tiles (6 = three gate/up pairs for SwiGLU); every chunk size has
+// its own branch-free instantiation of the loop.
+template <int EPI, typename OutT, int MT, bool FP8>
+__global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_args a, int units_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ds_smem[];
+    f32x4_t* slab = reinterpret_cast<f32x4_t*>(ds_smem);      // [wave][unit in round][tile of unit][lane]
+    constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
+    constexpr int NTW = EPI == VCLA_EPI_SWIGLU ? 6 : 4;
+    constexpr int KS = FP8 ? 2 : 1;
+    DsCtx c;
+    c.lane = threadIdx.x & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, g = blockIdx.x;
+    const int t_beg = (int)((int64_t)g * units_total / G) * TPU, t_end = (int)((int64_t)(g + 1) * units_total / G) * TPU;
+    const int KST = a.K / (32 * KS);                           // stages along K
+    c.nst = (KST - c.wave + DS_WAVES - 1) / DS_WAVES;          // stages of this wave
+    c.mt_c = (a.M + 15) >> 4;                                  // == MT (the launcher instantiates MT = ceil(M/16))
+    const int n_pad = (a.N + 127) / 128 * 128;
+    c.w_tile_bytes = (unsigned)a.K * (FP8 ? 16u : 32u);
+    c.rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A_frag), 0, (int)((int64_t)c.mt_c * 16 * a.K * 2), 0x00020000);
+    c.rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(FP8 ? a.W_q8_frag : a.W_frag), 0, (int)((int64_t)(n_pad / 16) * c.w_tile_bytes), 0x00020000);
+    c.voff = c.lane * 16;
+    c.a_stage_bytes = (unsigned)(KS * c.mt_c) << 10;
+
+    for (int c0 = t_beg; c0 < t_end; c0 += NTW) {
+        const int nt = (t_end - c0) < NTW ? (t_end - c0) : NTW;     // tiles of this chunk (workgroup-uniform)
+        if constexpr (TPU == 2) {
+            if (nt == 6) ds_chunk<EPI, OutT, MT, 6, FP8>(a, c, c0, slab);
+            else if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(a, c, c0, slab);
+            else ds_chunk<EPI, OutT, MT, 2, FP8>(a, c, c0, slab);
+        } else {
+            if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(a, c, c0, slab);
+            else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(a, c, c0, slab);
+            else if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8>(a, c, c0, slab);
+            else ds_chunk<EPI, OutT, MT, 1, FP8>(a, c, c0, slab);
+        }
+    }
+}
+
+template <int EPI, typename OutT, int MT, bool FP8>
+static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
+    constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
+    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t);   // 64 KiB (128 KiB for SwiGLU)
+    auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
+    VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
+    return VCLA_OK;
+}
+
+template <int EPI, typename OutT, bool FP8>
+static int ds_pick_mt(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
+    const int mt = (a->M + 15) / 16;
+    if (mt <= 1) return ds_launch<EPI, OutT, 1, FP8>(a, units, grid, s);
+    if (mt == 2) return ds_launch<EPI, OutT, 2, FP8>(a, units, grid, s);
+    if (mt == 3) return ds_launch<EPI, OutT, 3, FP8>(a, units, grid, s);
+    return ds_launch<EPI, OutT, 4, FP8>(a, units, grid, s);
+}
+
+// called by vcla_gemm (gemm.hip) for kernel 9; arguments were validated there
+int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
+    const bool fp8 = a->W_q8_frag != nullptr;
+    const bool swiglu = a->epilogue == VCLA_EPI_SWIGLU;
+    const int tiles = (a->N + 15) / 16;                        // W_frag rows exist up to N_pad (multiple of 128) >= tiles * 16
+    const int units = swiglu ? tiles / 2 : tiles;              // SwiGLU: N % 32 == 0
+    static const int grid_env = getenv("VCLA_DS_GRID") ? atoi(getenv("VCLA_DS_GRID")) : 256;   // one workgroup per CU
+    const int grid = units < grid_env ? units : grid_env;
+#define DS_GO(EPI_, OUT_) return fp8 ? ds_pick_mt<EPI_, OUT_, true>(a, units, grid, s) : ds_pick_mt<EPI_, OUT_, false>(a, units, grid, s)
+    if (swiglu) { DS_GO(VCLA_EPI_SWIGLU, bf16_t); }
+    if (a->out_f32) { DS_GO(VCLA_EPI_NONE, float); }
+    DS_GO(VCLA_EPI_NONE, bf16_t);
+#undef DS_GO
+}

@@ -126,6 +126,33 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, i
     }
 }
 
+
+// LlamaRMSNorm of <= 64 bf16 rows, output in the MFMA-fragment-major layout the streaming decode GEMM reads
+// (vcla_gemm_args.A_frag: [cols/32][MT][64 lanes][8], element (m, k) in fragment (k/32, m/16), lane ((k%32)/8)*16 + m%16,
+// slot k%8).  Staging, statistics and rounding follow rmsnorm_kernel instruction for instruction (bit-identical values); only
+// the store address differs: a thread's 8 consecutive columns are one 16-byte fragment slot.  gamma == NULL: plain re-layout.
+__global__ __launch_bounds__(256) void rmsnorm_pack_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                           bf16_t* __restrict__ y, int cols, int mt, float eps, int vec_ok) {
+    __shared__ float row[NORM_MAX_COLS];
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    stage_row<bf16_t>(x + (int64_t)r * ldx, row, cols, vec_ok);
+    __syncthreads();
+    float rstd = 1.f;
+    if (gamma) {
+        float q = 0.f;
+        for (int c = threadIdx.x; c < cols; c += 256) q += row[c] * row[c];
+        rstd = rsqrtf(block_sum_256(q, red) / (float)cols + eps);
+    }
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gamma ? gamma[c + e] * Act<bf16_t>::rnd(row[c + e] * rstd) : row[c + e];
+        bf16_t* dst = y + ((((int64_t)(c >> 5) * mt + (r >> 4)) * 64 + ((c & 31) >> 3) * 16 + (r & 15)) << 3);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+}
+
 // ViT input assembly: row (b, n): n == 0 -> class embedding, else patch embed (b, n-1); + position emb; pre-LN
 template <typename T>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ patch, const float* __restrict__ cls,
@@ -199,6 +226,19 @@ extern "C" int vcla_rmsnorm(const void* x, int64_t ldx, const float* gamma, void
     else
         rmsnorm_kernel<bf16_t><<<rows, 256, 0, s>>>((const bf16_t*)x, ldx, gamma, (bf16_t*)y, ldy, cols, eps, v);
     VCLA_CHECK_LAUNCH("rmsnorm_kernel");
+    return VCLA_OK;
+}
+
+
+extern "C" int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma, void* y_frag, int rows, int cols, float eps,
+                                 void* stream) {
+    VCLA_REQUIRE(rows >= 0 && rows <= 64 && cols > 0 && cols <= NORM_MAX_COLS && cols % 32 == 0, VCLA_ERR_BAD_SHAPE,
+                 "rmsnorm_pack: rows=%d (max 64) cols=%d (multiple of 32, max %d)", rows, cols, NORM_MAX_COLS);
+    VCLA_REQUIRE(x && y_frag && vcla_aligned(y_frag, 16), VCLA_ERR_BAD_ARG, "rmsnorm_pack: null / misaligned pointer");
+    if (rows == 0) return VCLA_OK;
+    const int v = vec4_ok(x, ldx, cols, VCLA_BF16);
+    rmsnorm_pack_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, gamma, (bf16_t*)y_frag, cols, (rows + 15) / 16, eps, v);
+    VCLA_CHECK_LAUNCH("rmsnorm_pack_kernel");
     return VCLA_OK;
 }
 

@@ -147,6 +147,45 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(float* __restric
         }
     }
     __syncthreads();
+    if (s_ncand > SAMPLE_CAP) {
+        // Rare: more than SAMPLE_CAP candidates (a run of equal scores at the k-th value; HF would keep all of them).  The
+        // arrival-order compaction above would then drop an arbitrary subset, so redo it deterministically: every key
+        // strictly above the threshold first (fewer than k of those, by construction of the bisection), then the keys tied
+        // around the threshold in ASCENDING token id until the capacity is reached.
+        __shared__ int s_wcnt[SAMPLE_THREADS / 64];
+        __syncthreads();
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < SAMPLE_PER_THREAD; ++j) {
+            const bool take = key[j] > lo;
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncand, __popcll(m));
+                base = __shfl(base, 0, 64);
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (take) { s_cv[slot] = funkey(key[j]) / a.temperature; s_ci[slot] = tid + j * SAMPLE_THREADS; }
+            }
+        }
+        __syncthreads();
+        int filled = s_ncand;                      // < k <= SAMPLE_CAP / 2, identical in every thread
+#pragma unroll 1
+        for (int j = 0; j < SAMPLE_PER_THREAD && filled < SAMPLE_CAP; ++j) {   // token id = tid + j * 1024: ascending in (j, tid)
+            const bool take = key[j] <= lo && key[j] >= lo_c && key[j] > 0x007fffffu;
+            const unsigned long long m = __ballot(take);
+            if (lane == 0) s_wcnt[tid >> 6] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < SAMPLE_THREADS / 64; ++w) { const int c = s_wcnt[w]; before += w < (tid >> 6) ? c : 0; total += c; }
+            const int slot = filled + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (take && slot < SAMPLE_CAP) { s_cv[slot] = funkey(key[j]) / a.temperature; s_ci[slot] = tid + j * SAMPLE_THREADS; }
+            filled += total;
+            __syncthreads();
+        }
+        if (tid == 0) s_ncand = filled < SAMPLE_CAP ? filled : SAMPLE_CAP;
+        __syncthreads();
+    }
     const int nc0 = s_ncand < SAMPLE_CAP ? s_ncand : SAMPLE_CAP;
     // rank sort, descending value; ties in DESCENDING index = the reverse of the stable ascending sort HF's top-p cut walks
     // (torch.sort on the scores), so a cut that falls inside a group of equal scores drops the lower token ids first

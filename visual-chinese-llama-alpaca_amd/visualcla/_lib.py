@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("W_frag", C.c_void_p),
         ("W_q8", C.c_void_p), ("W_q8_frag", C.c_void_p), ("w_scale", C.c_void_p),
         ("post_norm_gamma", C.c_void_p), ("post_norm_eps", C.c_float), ("post_norm_out", C.c_void_p), ("post_norm_ld", C.c_int64),
+        ("A_frag", C.c_void_p), ("C_frag", C.c_void_p),
     ]
 
 
@@ -107,6 +108,7 @@ SYMBOLS = {
     "vcla_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     "vcla_rmsnorm": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     "vcla_gemm": (_i, [C.POINTER(GemmArgs), _i, _vp]),
+    "vcla_rmsnorm_pack": (_i, [_vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
     "vcla_gemv_tune": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
@@ -115,7 +117,7 @@ SYMBOLS = {
                                    C.POINTER(C.c_float), _vp, _i, _vp]),
     "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _vp]),
+    "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
     "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
     "vcla_sample": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(SampleArgs), _vp, _vp]),
     "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
@@ -207,18 +209,50 @@ def rmsnorm(x, gamma, eps, out=None):
     return out.view(x.shape)
 
 
+def to_frag(a: torch.Tensor) -> torch.Tensor:
+    """[M, K] bf16 row-major -> the fragment-major activation layout of vcla_gemm_args.A_frag, [K/32, ceil(M/16), 64, 8]
+    (host-side twin of vcla_rmsnorm_pack(gamma=NULL); rows past M are zero)."""
+    M, K = a.shape
+    mt = (M + 15) // 16
+    ap = torch.zeros(mt * 16, K, dtype=a.dtype, device=a.device)
+    ap[:M] = a
+    return ap.view(mt, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(K // 32, mt, 64, 8)
+
+
+def from_frag(f: torch.Tensor, M: int) -> torch.Tensor:
+    """inverse of to_frag: [K/32, MT, 64, 8] -> [M, K]"""
+    ks, mt = f.shape[0], f.shape[1]
+    return f.view(ks, mt, 4, 16, 8).permute(1, 3, 0, 2, 4).contiguous().view(mt * 16, ks * 32)[:M]
+
+
+def rmsnorm_pack(x, gamma, eps, out=None):
+    """[M <= 64, K] bf16 -> fragment-major RMSNorm(x) (gamma None: plain re-layout), [K/32, ceil(M/16), 64, 8]"""
+    M, K = x.shape
+    if out is None:
+        out = torch.zeros(K // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=x.device)
+    check(load().vcla_rmsnorm_pack(ptr(x), x.stride(0), ptr(gamma), ptr(out), M, K, float(eps), stream_ptr()))
+    return out
+
+
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
          group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None,
-         post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None):
-    """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out]."""
+         post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None, a_frag=None, c_frag=None, m=None):
+    """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out].  a_frag ([K/32, MT, 64, 8], with m = M) selects
+    the streaming decode kernel; c_frag (same layout over N_out) receives a fragment-major copy of the output."""
     lib = load()
-    M, K = a.shape
+    if a is None:
+        M, K = int(m), a_frag.shape[0] * 32
+        adt, adev = torch.bfloat16, a_frag.device
+    else:
+        M, K = a.shape
+        adt, adev = a.dtype, a.device
     n_out = n // 2 if epilogue == EPI_SWIGLU else n
     if out is None:
-        odt = torch.float32 if (out_f32 or a.dtype == torch.float32) else torch.bfloat16
-        out = torch.empty(M, n_out, dtype=odt, device=a.device)
+        odt = torch.float32 if (out_f32 or adt == torch.float32) else torch.bfloat16
+        out = torch.empty(M, n_out, dtype=odt, device=adev)
     args = GemmArgs()
-    args.A, args.lda = ptr(a), a.stride(0)
+    args.A, args.lda = ptr(a), (a.stride(0) if a is not None else 0)
+    args.A_frag, args.C_frag = ptr(a_frag), ptr(c_frag)
     args.W, args.bias = ptr(w_packed), ptr(bias)
     args.residual, args.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
     args.C, args.ldc = ptr(out), out.stride(0)
@@ -234,7 +268,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     if post_norm_gamma is not None:
         args.post_norm_gamma, args.post_norm_eps = ptr(post_norm_gamma), float(post_norm_eps)
         args.post_norm_out, args.post_norm_ld = ptr(post_norm_out), post_norm_out.stride(0)
-    check(lib.vcla_gemm(C.byref(args), dtype_code(a.dtype), stream_ptr()))
+    check(lib.vcla_gemm(C.byref(args), dtype_code(adt), stream_ptr()))
     return out
 
 

@@ -174,7 +174,9 @@ def chat_in_stream(model, image: Union[str, "Image.Image", torch.Tensor], text: 
     response = ""
     old_history = deepcopy(history)
 
-    params = generation_config.to_dict()
+    # to_dict() spells out every unset field as None; passed as keyword arguments those Nones would override the model's
+    # own eos / pad ids (explicit kwargs win in generate()), and the stream would run to max_new_tokens: drop them
+    params = {k: v for k, v in generation_config.to_dict().items() if v is not None}
     params["input_ids"] = enc.input_ids
     params["attention_mask"] = enc.attention_mask
     params["pixel_values"] = enc.pixel_values

@@ -180,7 +180,21 @@ class VisualCLAModel:
                 config.vision_config = sub_cfg.get("vision_config", sub_cfg)
             for k, v in cls._read_checkpoint_dir(d).items():
                 sd[prefix + k] = v
-        return cls.from_state_dict(config, sd, default_device, torch_dtype)
+        model = cls.from_state_dict(config, sd, default_device, torch_dtype)
+        model.generation_config = cls._load_generation_config(os.path.join(path, "text_encoder"), config.text_config)
+        return model
+
+    @staticmethod
+    def _load_generation_config(text_dir: Optional[str], text_config: dict):
+        """The decoder's generation defaults (eos / bos / pad ids): `<text dir>/generation_config.json` when the checkpoint
+        ships one, else the ids in the LLaMA config.json -- what `LlamaForCausalLM.from_pretrained` leaves in
+        `model.generation_config` and HF's generate() falls back on for fields the caller's config leaves at None
+        (the reference's DEFAULT_GENERATION_CONFIG has eos_token_id=None, modeling_utils.py:36-47)."""
+        from transformers import GenerationConfig
+        if text_dir and os.path.isfile(os.path.join(text_dir, "generation_config.json")):
+            return GenerationConfig.from_pretrained(text_dir)
+        ids = {k: text_config.get(k) for k in ("eos_token_id", "bos_token_id", "pad_token_id") if text_config.get(k) is not None}
+        return GenerationConfig(**ids) if ids else None
 
     @classmethod
     def from_vision_text_pretrained(cls, vision_model_name_or_path: str = None, text_model_name_or_path: str = None,
@@ -230,7 +244,9 @@ class VisualCLAModel:
                 fold_lora(sd, torch.load(bin_path, map_location="cpu", weights_only=True), json.load(f))
             # modules_to_save grows the embeddings to the tokenizer's size (merge script :68-75)
             visualcla_config.text_config["vocab_size"] = sd["text_model.model.embed_tokens.weight"].shape[0]
-        return cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
+        model = cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
+        model.generation_config = cls._load_generation_config(text_model_name_or_path, visualcla_config.text_config)
+        return model
 
     # ------------------------------------------------------------------ nn.Module-like surface
     @property
@@ -423,8 +439,13 @@ class VisualCLAModel:
         """-> (inputs_embeds [B, T', D], attention-mask extension length).  Handles both placements."""
         lib = _lib.load()
         t = self.config.text_config
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [batch, seq], got {tuple(input_ids.shape)}")
+        input_ids = input_ids.long()               # the kernel reads int64 ids
         B, T = input_ids.shape
         V, D = t["vocab_size"], t["hidden_size"]
+        if image_embeds is not None and image_embeds.shape[0] != B:
+            raise ValueError(f"pixel_values hold {image_embeds.shape[0]} images for {B} prompts")
         if bool(((input_ids < 0) | (input_ids >= V)).any()):
             raise ValueError("input_ids contain ids outside the vocabulary")
         Q, img_pos, extra = 0, None, 0
@@ -539,6 +560,14 @@ class VisualCLAModel:
         from transformers import GenerationConfig
         import copy
         gc = copy.deepcopy(generation_config or self.generation_config or GenerationConfig())
+        if generation_config is not None and self.generation_config is not None:
+            # HF generate(): special-token fields the caller's config leaves at None come from the model's own generation
+            # config (hf:generation/utils.py _prepare_generation_config) -- without this chat() under the reference's
+            # DEFAULT_GENERATION_CONFIG (eos_token_id=None) would never stop at </s>.  Explicit keyword arguments below
+            # still override (eos_token_id=None in a call disables the stop, as the benchmark does).
+            for k in ("eos_token_id", "bos_token_id", "pad_token_id"):
+                if getattr(gc, k, None) is None and getattr(self.generation_config, k, None) is not None:
+                    setattr(gc, k, getattr(self.generation_config, k))
         for k in list(kwargs.keys()):
             if hasattr(gc, k) and k not in ("input_ids", "pixel_values", "attention_mask"):
                 setattr(gc, k, kwargs.pop(k))
@@ -653,20 +682,21 @@ class VisualCLAModel:
                 with torch.cuda.device(self._device):
                     first = _lib.sample(logits, samp, n_hist=0)
             else:
-                first = _lib.argmax(logits)
+                with torch.cuda.device(self._device):
+                    first = _lib.argmax(logits)
             out[0] = first
             done_at = n_new
             step, chunk = 1, (n_new if not eos else 32)
             self._pos_dev.zero_()
             # hipGraph capture is illegal on the legacy default stream: hop onto a side stream for the loop
             cur_stream = torch.cuda.current_stream(self._device)
+            eos_t = torch.tensor(eos, device=self._device) if eos else None   # created BEFORE the side stream forks off
             side = None
             if use_graph and cur_stream.cuda_stream == 0:
                 if getattr(self, "_side_stream", None) is None:
                     self._side_stream = torch.cuda.Stream(device=self._device)
                 side = self._side_stream
                 side.wait_stream(cur_stream)
-            eos_t = torch.tensor(eos, device=self._device) if eos else None
             with torch.cuda.device(self._device), torch.cuda.stream(side if side is not None else cur_stream):
                 # position of decode step i's input token = T + *pos_dev; the counter runs 0,1,2,... across chunks so
                 # the captured graph (keyed on buffers + pos0) is reused for the whole generate() call
