@@ -151,6 +151,17 @@ typedef struct vcla_gemm_args {
     /* optional second output in the same fragment-major layout, [N_out/32][ceil(M/16)][64][8] bf16 (N_out % 32 == 0): feeds the
        next streaming GEMM (SwiGLU activations -> down_proj).  When set, `C` may be NULL (no row-major copy is stored). */
     void* C_frag;
+    /* Deferred RMSNorm across two streaming GEMMs (LLaMA batch decode: o_proj -> post_attention_layernorm -> gate/up, down_proj ->
+       next input_layernorm -> qkv).  PRODUCER side: c_frag_gamma [N] makes C_frag hold bf16(gamma[n] * C[m, n]) and c_row_ssq
+       [M][ceil(N/16)] receives, per row and 16-column tile, the sum of squares of the stored (rounded) C values.  CONSUMER side:
+       a_row_ssq (the producer's c_row_ssq, a_row_ssq_parts partial sums per row) turns the accumulator of row m into
+       acc * rsqrt(sum(a_row_ssq[m, :]) / K + a_norm_eps) before bias / activation: together
+       W . (gamma * x) * rstd(x) = W . RMSNorm(x), with no norm launch in between.  Kernel 9 only. */
+    const float* c_frag_gamma;
+    float* c_row_ssq;
+    const float* a_row_ssq;
+    int a_row_ssq_parts;
+    float a_norm_eps;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

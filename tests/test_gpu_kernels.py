@@ -713,3 +713,37 @@ def test_attn_decode_fragment_major_output(lib, B, H, d, pos):
         outs.append(out)
     torch.cuda.synchronize()
     assert torch.equal(lib.from_frag(outs[1], B), outs[0])
+
+
+@pytest.mark.parametrize("M,D,N2,epi2", [(64, 4096, 12288, 0), (64, 4096, 22016, 3), (33, 512, 1408 * 2, 3), (2, 256, 320, 0)])
+def test_gemm_dstream_deferred_rmsnorm(lib, M, D, N2, epi2):
+    """o_proj / down_proj -> RMSNorm -> next GEMM without a norm launch: the producer stores gamma * x fragment-major plus per-row
+    partial sums of squares (c_frag_gamma, c_row_ssq), the consumer scales its accumulators by rstd (a_row_ssq):
+    W . bf16(gamma * x) * rstd(x).  One bf16 rounding fewer than HF's gamma * bf16(x * rstd) -- compared against both."""
+    from visualcla.weights import to_fragment_major
+    g = torch.Generator().manual_seed(M + D + N2)
+    a = bf16r(torch.randn(M, D, generator=g))
+    w1 = bf16r(torch.randn(D, D, generator=g) * 0.03)
+    res = bf16r(torch.randn(M, D, generator=g))
+    gamma = bf16r(1 + 0.1 * torch.randn(D, generator=g))
+    w2 = bf16r(torch.randn(N2, D, generator=g) * 0.05)
+    w1p, w2p = _pack(w1), _pack(w2)
+    xd = res.to(DEV, torch.bfloat16)
+    cf = torch.zeros(D // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV)
+    ssq = torch.zeros(M, D // 16, dtype=torch.float32, device=DEV)
+    lib.gemm(None, w1p, D, residual=xd, out=xd, force_kernel=9, a_frag=lib.to_frag(a.to(DEV, torch.bfloat16)), m=M,
+             w_frag=to_fragment_major(w1p), c_frag=cf, c_frag_gamma=gamma.to(DEV), c_row_ssq=ssq)
+    torch.cuda.synchronize()
+    x = xd.float().cpu()                                               # the residual stream as stored (bf16)
+    _cmp("deferred_norm.x", x, res + a @ w1.t(), atol=2e-3, rtol=8e-3)
+    assert torch.equal(lib.from_frag(cf, M).float().cpu(), bf16r(gamma * x))
+    _cmp("deferred_norm.ssq", ssq.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
+    rstd = torch.rsqrt((x * x).mean(1, keepdim=True) + 1e-6)
+    got = lib.gemm(None, w2p, N2, epilogue=epi2, force_kernel=9, a_frag=cf, m=M, w_frag=to_fragment_major(w2p), a_row_ssq=ssq, a_norm_eps=1e-6)
+    w2s = w2
+    ref = _gemm_ref(bf16r(gamma * x) * rstd, w2s, None, epi2, None)      # what the kernels compute, in fp32
+    _cmp(f"deferred_norm.consumer[{M}x{N2}x{D},epi{epi2}]", got, ref, atol=2e-3, rtol=8e-3)
+    hf = _gemm_ref(O.llama_rmsnorm(xd.cpu(), gamma.to(torch.bfloat16), 1e-6).float(), w2, None, epi2, None)   # HF's rounding order
+    err = (got.float().cpu() - hf).abs()
+    _report(f"deferred rmsnorm vs HF order [{M}x{N2}x{D},epi{epi2}]: max {err.max().item():.3e} mean {err.mean().item():.3e} (ref absmax {hf.abs().max().item():.2e})")
+    assert err.max().item() <= 2e-2 * max(1.0, hf.abs().max().item())

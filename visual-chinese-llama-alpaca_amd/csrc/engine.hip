@@ -345,6 +345,7 @@ struct LlamaWs {
     float* logits;
     int64_t* ids;
     void* splitk;
+    float* ssq;     // [64][t_hidden / 16] per-row partial sums of squares (deferred RMSNorm of the streaming decode GEMMs)
 };
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -361,6 +362,7 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.logits = (float*)b.take((size_t)B * c.t_vocab * 4);
     t.ids = (int64_t*)b.take((size_t)B * 8);
     t.splitk = b.take(SPLITK_WS_BYTES);
+    t.ssq = (float*)b.take((size_t)64 * ((c.t_hidden + 15) / 16) * 4);
     if (w) *w = t;
     return b.off + 256;
 }
@@ -402,8 +404,10 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
 
 // streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
 static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
-                   void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0) {
+                   void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0, const float* a_ssq = nullptr,
+                   int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr) {
     vcla_gemm_args a{};
+    a.a_row_ssq = a_ssq; a.a_row_ssq_parts = a_parts; a.a_norm_eps = ctx->c.t_eps; a.c_frag_gamma = c_gamma; a.c_row_ssq = c_ssq;
     a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
     if (g_decode_step && wv.q8f && wv.s8) { a.W_q8_frag = wv.q8f; a.w_scale = wv.s8; }
@@ -520,14 +524,29 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     static const int ds_env = getenv("VCLA_DSTREAM") ? atoi(getenv("VCLA_DSTREAM")) : 1;
     const bool has_frag = (L.vqkv.frag && L.vo.frag && L.vgu.frag && L.vd.frag) || (L.vqkv.q8f && L.vo.q8f && L.vgu.q8f && L.vd.q8f);
     if (ds_env && T == 1 && dt == VCLA_BF16 && M >= 2 && M <= 64 && has_frag && D % 32 == 0 && c.t_inter % 32 == 0) {
-        RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
-        RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE));
+        // RMSNorm is deferred across the GEMMs (VCLA_DS_DEFER=0: a vcla_rmsnorm_pack launch per norm instead): o_proj / down_proj
+        // store gamma * x fragment-major next to the residual stream plus per-row partial sums of squares, and the consuming
+        // GEMM scales its accumulators by rstd(x): W . (gamma * x) * rstd = W . RMSNorm(x).  5 launches per layer.
+        static const int defer_env = getenv("VCLA_DS_DEFER") ? atoi(getenv("VCLA_DS_DEFER")) : 1;
+        const bool defer = defer_env != 0 && D % 16 == 0;
+        const int parts = D / 16;
+        const float scale_ = 1.0f / sqrtf((float)d);
+        if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
+        RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
+                    defer && h_ready ? w.ssq : nullptr, parts));
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
-                                   1.0f / sqrtf((float)d), dt, /*out_frag=*/1, s));
-        RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, nullptr, M, D, D, VCLA_EPI_NONE));
-        RUN(vcla_rmsnorm_pack(w.x, D, L.ln2g, w.h, M, D, c.t_eps, s));
-        RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
-        RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, nullptr, M, D, c.t_inter, VCLA_EPI_NONE));
+                                   scale_, dt, /*out_frag=*/1, s));
+        if (defer) {
+            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq));
+            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, parts));
+            RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, next_gamma ? w.h : nullptr, M, D, c.t_inter, VCLA_EPI_NONE, 0, nullptr, 0,
+                        next_gamma, next_gamma ? w.ssq : nullptr));
+        } else {
+            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, nullptr, M, D, D, VCLA_EPI_NONE));
+            RUN(vcla_rmsnorm_pack(w.x, D, L.ln2g, w.h, M, D, c.t_eps, s));
+            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
+            RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, nullptr, M, D, c.t_inter, VCLA_EPI_NONE));
+        }
         return VCLA_OK;
     }
     // M <= 8 rows (decode): the GEMV kernel applies RMSNorm in its prologue -- no norm launch, no normalised copy.
@@ -627,8 +646,11 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
                            ((L0.vqkv.frag && L0.vo.frag && L0.vgu.frag && L0.vd.frag) || (L0.vqkv.q8f && L0.vo.q8f && L0.vgu.q8f && L0.vd.q8f));
     if (ds_layers && (ctx->vlm.frag || ctx->vlm.q8f)) {
         // streaming layers leave the residual stream in w.x: final norm -> fragment-major, lm_head streamed the same way
-        RUN(vcla_rmsnorm_pack(w.x, D, ctx->norm_g, w.h, B, D, c.t_eps, s));
-        RUN(gemm_ds(ctx, s, w.h, ctx->lm_head, ctx->vlm, nullptr, 0, lg, c.t_vocab, nullptr, B, c.t_vocab, D, VCLA_EPI_NONE, 1));
+        static const int defer_env = getenv("VCLA_DS_DEFER") ? atoi(getenv("VCLA_DS_DEFER")) : 1;
+        const bool defer = defer_env != 0 && D % 16 == 0;     // the last down_proj left gamma_final * x and its row statistics in w.h / w.ssq
+        if (!defer) RUN(vcla_rmsnorm_pack(w.x, D, ctx->norm_g, w.h, B, D, c.t_eps, s));
+        RUN(gemm_ds(ctx, s, w.h, ctx->lm_head, ctx->vlm, nullptr, 0, lg, c.t_vocab, nullptr, B, c.t_vocab, D, VCLA_EPI_NONE, 1,
+                    defer ? w.ssq : nullptr, D / 16));
     } else if (ds_layers) {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, B, D, c.t_eps, dt, s));
         RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));

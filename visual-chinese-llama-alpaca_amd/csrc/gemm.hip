@@ -1344,8 +1344,13 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                          !a->post_norm_gamma, VCLA_ERR_BAD_ARG, "gemm: the streaming kernel implements epilogues NONE / SWIGLU, no row regrouping, no fused norms");
         VCLA_REQUIRE(!a->C_frag || (!a->out_f32 && ((a->epilogue == VCLA_EPI_SWIGLU ? a->N / 2 : a->N) % 32 == 0) && vcla_aligned(a->C_frag, 16)),
                      VCLA_ERR_BAD_ARG, "gemm: C_frag needs a bf16 output whose width is a multiple of 32");
+        VCLA_REQUIRE(!a->c_frag_gamma || a->C_frag, VCLA_ERR_BAD_ARG, "gemm: c_frag_gamma without C_frag");
+        VCLA_REQUIRE(!a->c_row_ssq || (a->epilogue == VCLA_EPI_NONE && !a->out_f32 && a->N % 16 == 0), VCLA_ERR_BAD_ARG,
+                     "gemm: c_row_ssq needs epilogue NONE, a bf16 output and N %% 16 == 0");
+        VCLA_REQUIRE(!a->a_row_ssq || a->a_row_ssq_parts > 0, VCLA_ERR_BAD_ARG, "gemm: a_row_ssq needs a_row_ssq_parts > 0");
     } else {
-        VCLA_REQUIRE(a->A && a->C && !a->C_frag, VCLA_ERR_BAD_ARG, "gemm: A_frag / C_frag are implemented by the streaming kernel (9) only");
+        VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
+                     "gemm: A_frag / C_frag / deferred-norm fields are implemented by the streaming kernel (9) only");
     }
     VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");

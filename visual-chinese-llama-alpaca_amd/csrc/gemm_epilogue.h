@@ -68,12 +68,27 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                         if (n + r < n_out) v[r] += bf2f(rp[r]);
                 }
             }
+            if (a.c_row_ssq) {
+                // deferred RMSNorm, producer side: sum of squares of the ROUNDED values of this row over this 16-column tile
+                // (the 4 lanes l, l+16, l+32, l+48 hold the row's 16 columns); host guarantees N % 16 == 0 here
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float x = Act<OutT>::rnd(v[r]); q += x * x; }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (nq == 0) a.c_row_ssq[(int64_t)m * ((n_out + 15) >> 4) + (n >> 4)] = q;
+            }
             if (a.C_frag) {
                 // fragment-major copy for the next streaming GEMM (its K index = this output column n): the lane's 4
                 // consecutive columns are half of one 8-element operand fragment -> one 8-byte store (n_out % 32 == 0)
                 const int mt_c = (a.M + 15) >> 4;
                 bf16_t* fp = (bf16_t*)a.C_frag + ((((int64_t)(n >> 5) * mt_c + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7);
-                *reinterpret_cast<uint2*>(fp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                float f[4] = {v[0], v[1], v[2], v[3]};
+                if (a.c_frag_gamma) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] = a.c_frag_gamma[n + r] * Act<OutT>::rnd(v[r]);
+                }
+                *reinterpret_cast<uint2*>(fp) = make_uint2(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]));
             }
             if (!Cg) continue;
             OutT* cp = Cg + crow * a.ldc + n;

@@ -16,7 +16,8 @@
 //     D stages in flight; the hot loop is branch-free (the tile count is a template parameter, the K tail is peeled) so the
 //     compiler emits counted vmcnt waits; the partial tiles meet once, through LDS, after the stream (fixed summation order).
 // The activations (M x K bf16 <= 1.4 MB) are re-read by every workgroup from L2; that traffic (134 MB for K = 4096) rides under
-// the HBM stream (L2 ~34 TB/s).  Algorithmic bytes per launch = N_pad * K * 2 (bf16) or N_pad * K (fp8).
+// the HBM stream (L2 ~34 TB/s).  (Measured and dropped: starting every workgroup at a different K offset so that the 32 CUs
+// of an XCD do not ask the L2 for the same activation line at the same time -- no change; the ~20 B/clk a CU can ingest is the limit.)  Algorithmic bytes per launch = N_pad * K * 2 (bf16) or N_pad * K (fp8).
 #include "vcla_common.h"
 #include "gemm_epilogue.h"
 #include <stdlib.h>
@@ -35,11 +36,11 @@ __device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 
 // ring depth: as many stages in flight as fit a ~200-register budget next to the accumulators (acc = NT*MT*4 registers,
 // a stage = (KS*MT + NT)*4), a power of two where possible (K / 256 stages per wave is a power of two for K = 4096: the peeled
-// tail then issues no loads), at most 8
+// tail then issues no loads), at most 4
 constexpr int ds_depth(int MT, int NT, bool FP8) {
     const int acc = NT * MT * 4, st = ((FP8 ? 2 : 1) * MT + NT) * 4;
     const int d = ((FP8 ? 176 : 200) - acc) / st;   // fp8: the in-register conversion needs temporaries
-    return d >= 8 ? 8 : (d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1)));
+    return d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1));   // 4 stages x 8 waves already keep > 100 KiB per CU in flight
 }
 
 struct DsCtx {
@@ -50,10 +51,38 @@ struct DsCtx {
     int wave, lane, nst, mt_c;
 };
 
+// deferred RMSNorm, consumer side: rstd of every activation row from the producer's per-tile sums of squares.  Called once per
+// workgroup after the K loop of its first chunk: wave w owns rows 8w .. 8w+7, 8 lanes per row, every lane's loads issued back to
+// back (one L2 round trip, hidden behind the slab writes of the cross-wave reduction); fixed summation order (lane-strided
+// partial sums, xor-shuffle tree).  The result lands in LDS; the reduction's barrier publishes it to the other waves.
+__device__ __forceinline__ void ds_row_rstd(const vcla_gemm_args& a, const DsCtx& c, float* rstd_s) {
+    const int parts = a.a_row_ssq_parts;
+    const int r = c.wave * 8 + (c.lane >> 3), seg = c.lane & 7;
+    float q = 0.f;
+    if (r < a.M) {
+        const float* src = a.a_row_ssq + (int64_t)r * parts;
+        if ((parts & 31) == 0) {
+            const int per = parts >> 3;          // contiguous run of this lane, a multiple of 4
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = k * 4 < per ? *reinterpret_cast<const float4*>(src + seg * per + k * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+            for (int k = 32; k < per; k += 4) { const float4 t = *reinterpret_cast<const float4*>(src + seg * per + k); q += (t.x + t.y) + (t.z + t.w); }
+        } else {
+            for (int p = seg; p < parts; p += 8) q += src[p];
+        }
+    }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    q += __shfl_xor(q, 4, 64);
+    if (seg == 0 && r < 64) rstd_s[r] = r < a.M ? rsqrtf(q / (float)a.K + a.a_norm_eps) : 0.f;
+}
+
 // One chunk of NT weight tiles [c0, c0 + NT) x all rows, K stages wave, wave + 8, ... of this wave; then the cross-wave reduction
 // and the epilogue.  MT = 16-row tiles of A; FP8: W_q8_frag (two k-steps per 16-byte lane load) instead of W_frag.
 template <int EPI, typename OutT, int MT, int NT, bool FP8>
-__device__ __forceinline__ void ds_chunk(const vcla_gemm_args& a, const DsCtx& c, int c0, f32x4_t* slab) {
+__device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, float* rstd_s, bool first) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;       // tiles per epilogue unit (SwiGLU: gate tile + up tile)
     constexpr int KS = FP8 ? 2 : 1;
     constexpr int D = ds_depth(MT, NT, FP8);
@@ -123,6 +152,15 @@ __device__ __forceinline__ void ds_chunk(const vcla_gemm_args& a, const DsCtx& c
 
     // ---- the 8 K-interleaved partial tiles meet in LDS; wave w reduces and finishes epilogue unit (round base + w).
     // unit u of the chunk = (tile group jj = u / MT, row tile i = u % MT); SwiGLU units carry the gate and the up tile.
+    // Everything below reads the argument block through the kernarg segment pointer, laundered so that the optimiser cannot
+    // hoist the loads: the ~40 scalar registers of epilogue-only arguments are loaded HERE instead of being held -- and
+    // spilled -- across the K loop (gemm_dstream_kernel's first argument IS the vcla_gemm_args block, offset 0).
+    typedef const __attribute__((address_space(4))) vcla_gemm_args* kernarg_p;   // the argument block is the first kernel argument
+    kernarg_p ap_ = (kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap_));
+    vcla_gemm_args a;
+    __builtin_memcpy(&a, (const void*)ap_, sizeof(a));
+    if (first && a.a_row_ssq) ds_row_rstd(a, c, rstd_s);
     constexpr int NU = (NT / TPU) * MT;
 #pragma unroll
     for (int r0 = 0; r0 < NU; r0 += DS_ROUND) {
@@ -148,6 +186,11 @@ __device__ __forceinline__ void ds_chunk(const vcla_gemm_args& a, const DsCtx& c
                     sum[0][tt][0] += p[0]; sum[0][tt][1] += p[1]; sum[0][tt][2] += p[2]; sum[0][tt][3] += p[3];
                 }
             const int jj = u / MT, i = u - jj * MT;
+            if (a.a_row_ssq) {   // deferred RMSNorm, consumer side: the lane's 4 values belong to row i*16 + (lane & 15)
+                const float rs = rstd_s[i * 16 + (c.lane & 15)];
+#pragma unroll
+                for (int tt = 0; tt < TPU; ++tt) { sum[0][tt][0] *= rs; sum[0][tt][1] *= rs; sum[0][tt][2] *= rs; sum[0][tt][3] *= rs; }
+            }
             gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, c.lane);
         }
         __syncthreads();
@@ -161,6 +204,7 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     extern __shared__ __attribute__((aligned(16))) unsigned char ds_smem[];
     f32x4_t* slab = reinterpret_cast<f32x4_t*>(ds_smem);      // [wave][unit in round][tile of unit][lane]
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
+    float* rstd_s = reinterpret_cast<float*>(ds_smem + (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t));   // [64] behind the slabs
     constexpr int NTW = EPI == VCLA_EPI_SWIGLU ? 6 : 4;
     constexpr int KS = FP8 ? 2 : 1;
     DsCtx c;
@@ -181,14 +225,14 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     for (int c0 = t_beg; c0 < t_end; c0 += NTW) {
         const int nt = (t_end - c0) < NTW ? (t_end - c0) : NTW;     // tiles of this chunk (workgroup-uniform)
         if constexpr (TPU == 2) {
-            if (nt == 6) ds_chunk<EPI, OutT, MT, 6, FP8>(a, c, c0, slab);
-            else if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(a, c, c0, slab);
-            else ds_chunk<EPI, OutT, MT, 2, FP8>(a, c, c0, slab);
+            if (nt == 6) ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+            else if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+            else ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
         } else {
-            if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(a, c, c0, slab);
-            else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(a, c, c0, slab);
-            else if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8>(a, c, c0, slab);
-            else ds_chunk<EPI, OutT, MT, 1, FP8>(a, c, c0, slab);
+            if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+            else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+            else if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+            else ds_chunk<EPI, OutT, MT, 1, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
         }
     }
 }
@@ -196,7 +240,7 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
 template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
-    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t);   // 64 KiB (128 KiB for SwiGLU)
+    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU) + rstd[64]
     auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
