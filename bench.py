@@ -1,24 +1,32 @@
 #!/usr/bin/env python
-"""bench.py -- VisualCLA-7B hot path on MI355X: images/sec + output tokens/sec.
+"""bench.py -- VisualCLA-7B hot path on MI355X: output tokens/sec + images/sec, with both rooflines and the CPU baseline.
 
 One "step" = one pass of the hot path over one batch of synthetic requests:
     ViT-L/14 (224 px) -> Resampler -> projection -> splice -> LLaMA-7B prefill (T=128) -> 128-token greedy decode.
-Default workload = BASELINE.json configs[1] ("VisualCLA-7B bf16, batch=1 image, 128-token greedy decode on 1 MI355X"),
-per GPU; `--batch 64` selects configs[2].  Weights are random-init of the 7B architecture, inputs synthetic
-(SURVEY.md section 8d); inputs are resident in HBM before the timed region.
+Two workloads are timed per run (SURVEY.md section 8d "two regimes, report both"):
+  * configs[1] -- `value`: B = 1 request per GPU (BASELINE.json configs[1]; the latency / HBM-bound regime), EXACTLY --steps steps;
+  * configs[2] -- `images_per_sec`, `config2`: B = 64 requests per GPU (BASELINE.json configs[2]; ViT + Resampler throughput,
+    the MFMA-bound vision / prefill regime next to batch decode), a few steps of its own (--steps-b64).
+Weights are random-init of the 7B architecture, inputs synthetic and resident in HBM before the timed
+region.
 
-Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one process per GPU, full replica
-each, the batch is sharded by rank (weak scaling: per-GPU batch fixed); the only collective is one RCCL all-gather of
-the generated ids per step (inside the timed region).
+Multi-GPU: `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU, 127.0.0.1 rendezvous)
+unless it already runs under a launcher (WORLD_SIZE set), in which case it is one of the ranks.  Full replica per rank, the
+batch is sharded by rank (weak scaling: per-GPU batch fixed), the only collective is ONE RCCL all-gather of the generated ids
+per step, inside the timed region.  `--plumbing-check` runs the same launch / shard / gather / max-over-ranks path on CPU
+(gloo) with a token-pattern stand-in for the model: tests/test_host_cpu.py uses it; it measures nothing.
 
-Prints ONE JSON line on rank 0 with the throughput, a `roofline` object for the dominant kernel (the decode weight-
-streaming GEMV, measured live with HIP events) and a `cpu_baseline` object (the CPU oracle timed on this host).
+Prints ONE JSON line on rank 0: throughput, `roofline` (the dominant kernel of the timed configs[1] workload, HBM regime),
+`rooflines` (all regimes: whole-step decode bytes vs 8 TB/s for B = 1 and B = 64, the batch-decode weight-streaming GEMM, the
+ViT MFMA GEMM vs 2.5 PFLOP/s, the vision stack as a whole) and `cpu_baseline` (the CPU oracle timed on this host).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,19 +35,18 @@ for p in (ROOT, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+KV_BYTES_PER_TOKEN = 512 * 1024  # bf16 K + V of one context token over the 32 layers
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="images/prompts per GPU (1 = configs[1], 64 = configs[2])")
+    ap.add_argument("--batch", type=int, default=1, help="requests per GPU of the main timed workload (1 = configs[1], 64 = configs[2])")
+    ap.add_argument("--steps-b64", type=int, default=2, help="timed steps of the second workload (configs[2], B = 64 per GPU); 0 = skip it")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in decode")
@@ -48,77 +55,178 @@ def parse():
     ap.add_argument("--image-size", type=int, default=224, help="336 = BASELINE configs[4] patching (577 ViT tokens, position embedding grown bicubically)")
     ap.add_argument("--sample", action="store_true", help="decode under the reference's DEFAULT_GENERATION_CONFIG (sampling + "
                     "penalties, on-device sampler) instead of greedy; a side measurement, not BASELINE's metric")
-    ap.add_argument("--cpu-tokens", type=int, default=3, help="decode tokens in the bounded CPU sample")
-    return ap.parse_args()
+    ap.add_argument("--cpu-tokens", type=int, default=32, help="decode tokens of the CPU baseline run (32 = BASELINE configs[0], timed in full)")
+    ap.add_argument("--plumbing-check", action="store_true", help="CPU / gloo check of the multi-rank launch, sharding, gather and timing path (no model)")
+    return ap.parse_args(argv)
 
 
-def gemv_roofline(model, n_rep: int = 20):
-    """Dominant kernel of the B=1 workload: the gate/up SwiGLU GEMV with fused RMSNorm
-    (gemv_kernel<bf16,bf16,M=1,EPI_SWIGLU,R=4>; ~34 % of the decode time, 43 % of the weight bytes).  One launch streams
-    W_gu [2*11008, 4096] bf16 exactly once: algorithmic bytes = 180.4 MB.  The 32 layers' matrices are launched back to
-    back (5.8 GB footprint, so nothing is served from the 256 MB Infinity Cache) between two HIP events on the current
-    stream; achieved = bytes / mean launch duration (inter-launch gaps included -> a conservative figure)."""
-    from visualcla import _lib
-    t = model.config.text_config
-    D, I = t["hidden_size"], t["intermediate_size"]
-    P = model._packed
-    dev = model.device
-    x = torch.randn(1, D, device=dev).to(torch.bfloat16)
-    layers = t["num_hidden_layers"]
-    out = torch.empty(1, I, dtype=torch.bfloat16, device=dev)
-    alg_bytes = 2 * I * D * 2
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    def run():
-        for l in range(layers):
-            _lib.gemm(x, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, force_kernel=2,
-                      norm_gamma=P[f"llama.l{l}.ln2.g"], norm_eps=1e-6)
-    run()
+
+def respawn_ranks(args) -> int:
+    """`bench.py --gpus N` outside a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------- rooflines
+def _event_time(fn, reps: int):
+    """seconds per call of fn(), HIP events on the stream the kernels are launched on (torch's current stream)"""
+    import torch
+    fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n_rep):
-        run()
+    for _ in range(reps):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    total_ms = e0.elapsed_time(e1)
-    launches = n_rep * layers
-    avg_us = total_ms * 1e3 / launches
-    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE doubled
-    # per the gfx950 correction; tools/gpu_check.sh pmc -> profiles/r01_pmc_gemv1_*.txt).  Not collectable inside this run.
-    traffic, src = None, None
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the B = 1 gate/up GEMV from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    their own runs, FETCH_SIZE doubled per the gfx950 correction; tools/gpu_check.sh pmc).  Not collectable inside this run."""
+    import re
     try:
-        import re
         tot = 0.0
         for nm in ("fetch_size", "write_size"):
             m = re.search(r"-> ([0-9.]+) MB per launch", open(os.path.join(ROOT, "profiles", f"r01_pmc_gemv1_{nm}.txt")).read())
             tot += float(m.group(1)) * 1e6
-        traffic, src = int(tot), "profiles/r01_pmc_gemv1_{fetch,write}_size.txt (separate rocprofv3 --pmc passes)"
+        return int(tot), "profiles/r01_pmc_gemv1_{fetch,write}_size.txt (separate rocprofv3 --pmc passes)"
     except Exception:
-        pass
-    return {"bound": "hbm", "kernel": "gemv1_kernel<R=2,U=4,WPB=8,SWIGLU> (gate/up GEMV + fused RMSNorm, bf16)",
+        return None, None
+
+
+def gemv_roofline(model, n_rep: int = 20):
+    """Dominant kernel of the B = 1 workload: the gate/up SwiGLU GEMV with fused RMSNorm (gemv1_kernel<R=2,U=4,WPB=8,SWIGLU>; ~34 %
+    of the decode time, 43 % of the weight bytes).  One launch streams W_gu [2*11008, 4096] bf16 exactly once: algorithmic
+    bytes = 180.4 MB.  The 32 layers' matrices are launched back to back (5.8 GB footprint, so nothing is served from the 256 MB
+    Infinity Cache) between two HIP events; achieved = bytes / mean launch duration (inter-launch gaps included)."""
+    import torch
+    from visualcla import _lib
+    t = model.config.text_config
+    D, I, L = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"]
+    P = model._packed
+    x = torch.randn(1, D, device=model.device).to(torch.bfloat16)
+    out = torch.empty(1, I, dtype=torch.bfloat16, device=model.device)
+    alg_bytes = 2 * I * D * 2
+
+    def run():
+        for l in range(L):
+            _lib.gemm(x, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, force_kernel=2, norm_gamma=P[f"llama.l{l}.ln2.g"], norm_eps=1e-6)
+    sec = _event_time(run, n_rep) / L
+    achieved = alg_bytes / sec / 1e9
+    traffic, src = _pmc_traffic()
+    return {"bound": "hbm", "kernel": "gemv1_kernel<R=2,U=4,WPB=8,SWIGLU> (B=1 gate/up GEMV + fused RMSNorm, bf16)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": src, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
-            "launches_timed": launches}
+            "traffic": traffic, "traffic_source": src, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(sec * 1e6, 2),
+            "launches_timed": n_rep * L}
 
 
-def cpu_baseline(model, prompt_len: int, new_tokens: int, sample_tokens: int):
-    """The CPU oracle (kind 'port': oracle/visualcla_oracle.py, fp32, torch CPU kernels on all host cores) on a bounded
-    sample of the same request: 1 image through the vision stack + prefill of the T=128 prompt + `sample_tokens` decode
-    steps; tokens/s is scaled to the full 128-token request as 128 / (t_vision + t_prefill + 128 * t_step)."""
+def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
+    """Dominant kernel of the B = 64 decode step: the gate/up SwiGLU streaming GEMM (gemm_dstream_kernel, fragment-major W, M = 64
+    rows): 22016 x 4096 bf16 = 180.4 MB streamed once per launch, over the 32 layers' matrices back to back."""
+    import torch
+    from visualcla import _lib
+    t = model.config.text_config
+    D, I, L = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"]
+    P = model._packed
+    if f"llama.l0.wgu.f" not in P:
+        return None
+    af = _lib.to_frag(torch.randn(M, D, device=model.device).to(torch.bfloat16))
+    cf = torch.zeros(I // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=model.device)
+    out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
+    alg_bytes = 2 * I * D * 2
+
+    def run():
+        for l in range(L):
+            _lib.gemm(None, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, force_kernel=9, a_frag=af, m=M,
+                      w_frag=P[f"llama.l{l}.wgu.f"], c_frag=cf)
+    sec = _event_time(run, n_rep) / L
+    achieved = alg_bytes / sec / 1e9
+    return {"bound": "hbm", "kernel": f"gemm_dstream_kernel<SWIGLU,MT=4> (B={M} gate/up streaming GEMM, bf16)", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
+
+
+def vit_gemm_roofline(model, B: int = 64, n_rep: int = 20):
+    """MFMA regime: the ViT fc1 GEMM of the B = 64 workload (M = 64*257 = 16448 rows, N = 4096, K = 1024, quick-GELU epilogue;
+    the largest single kernel of the vision stack) through the product dispatch: algorithmic flops = 2 M N K per launch."""
+    import torch
+    from visualcla import _lib
+    v = model.config.vision_config
+    D, I = v["hidden_size"], v["intermediate_size"]
+    N = (v["image_size"] // v["patch_size"]) ** 2 + 1
+    M = B * N
+    P = model._packed
+    a = torch.randn(M, D, device=model.device).to(torch.bfloat16)
+    out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=model.device)
+    L = v["num_hidden_layers"]
+
+    def run():
+        for l in range(L):
+            _lib.gemm(a, P[f"vit.l{l}.w1"], I, bias=P[f"vit.l{l}.b1"], out=out, epilogue=_lib.EPI_QUICK_GELU, splitk_ws=ws)
+    sec = _event_time(run, n_rep) / L
+    flops = 2.0 * M * I * D
+    tf = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": f"gemm_mfma256_kernel<QUICK_GELU> (ViT fc1, M={M} N={I} K={D}, + its ragged-M tail launch)",
+            "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+            "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
+
+
+def step_rooflines(b1, b64, cfgd, fp8: bool):
+    """Whole-step figures, so the line cannot quote only its best kernel: decode bytes per step = all LLaMA linear weights +
+    lm_head read once (13.36 GB bf16 / 6.68 GB fp8, shared by the batch) + B * ctx * 512 KiB of KV cache (ctx = mean context
+    over the decode steps); vision flops = 179.2 GF per image at 224 px (ViT 162.0 + resampler 16.64 + projection 0.54)."""
+    T, n_new = cfgd["seq_len"], cfgd["new_tokens"]
+    w_bytes = 13.36e9 / (2 if fp8 else 1)
+    ctx = T + (n_new + 1) / 2.0
+    out = []
+    for tag, br in (("B=1", b1), ("B=64", b64)):
+        if not br:
+            continue
+        B = br["batch_per_gpu"]
+        bytes_step = w_bytes + B * ctx * KV_BYTES_PER_TOKEN
+        ach = bytes_step / (br["breakdown_ms"]["decode_ms_per_token_step"] * 1e-3) / 1e9
+        out.append({"bound": "hbm", "kernel": f"whole decode step, {tag} per GPU (all kernels + launch gaps)", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_step": int(bytes_step), "ms_per_step": br["breakdown_ms"]["decode_ms_per_token_step"]})
+        if cfgd.get("image_size", 224) == 224:
+            fl = B * 179.2e9
+            tf = fl / (br["breakdown_ms"]["vision_ms"] * 1e-3) / 1e12
+            out.append({"bound": "mfma", "kernel": f"whole vision stack (ViT + resampler + projection), {tag} per GPU", "achieved": round(tf, 1),
+                        "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                        "alg_flops": fl, "ms": br["breakdown_ms"]["vision_ms"]})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(model, prompt_len: int, n_tokens: int):
+    """BASELINE configs[0] on this host: the CPU oracle (kind "port": oracle/visualcla_oracle.py = the reference's glue + the
+    transformers arithmetic restated, pinned to the reference's own outputs in tests/golden; /root/reference itself does not
+    exist on the GPU box) runs ONE request end to end in fp32 -- vision stack, prefill of the T = 128 prompt, `n_tokens` greedy
+    decode steps, all timed, nothing extrapolated.  32 threads: one NUMA domain's worth; torch's CPU kernels collapse when spread
+    over all 256 SMT threads of the 2-socket host (measured 28 s/token at 256 threads vs 0.8 s at 32)."""
+    import torch
     from oracle import visualcla_oracle as O   # the ONLY place this file touches oracle/: the CPU leg is the oracle, timed
     cfg_o = O.cfg_7b()
-    # one NUMA domain's worth of threads: torch's CPU kernels collapse when spread over all 256 SMT threads of the
-    # GPU box's 2-socket host (measured: 28 s/token at 256 threads)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     t0 = time.time()
     W = model.state_dict()                      # bf16-rounded values, fp32 on the host (~27 GB)
     t_unpack = time.time() - t0
     px, ids, mask = O.make_inputs(cfg_o, 1, prompt_len)
     with torch.no_grad():
-        t0 = time.time()
+        t_begin = time.time()
         img = O.image_embeds(px, W, cfg_o)
-        t_vis = time.time() - t0
+        t_vis = time.time() - t_begin
         x = O.embed_and_splice(ids, img, W, cfg_o)
         cache = [None] * cfg_o.text.num_hidden_layers
         t0 = time.time()
@@ -127,28 +235,89 @@ def cpu_baseline(model, prompt_len: int, new_tokens: int, sample_tokens: int):
         t_pre = time.time() - t0
         t0 = time.time()
         past = prompt_len
-        for _ in range(sample_tokens):
+        produced = 1                              # the prefill's argmax is the first new token
+        for _ in range(n_tokens - 1):
             nxt = logits.argmax(-1)
             e = W["text_model.model.embed_tokens.weight"][nxt][:, None, :]
             m = torch.ones(1, past + 1, dtype=torch.int64)
             h = O.llama_forward(e, W, cfg_o.text, m, cache, past)
             logits = O.lm_head(h, W)[:, 0]
             past += 1
-        t_step = (time.time() - t0) / max(sample_tokens, 1)
-    total = t_vis + t_pre + new_tokens * t_step
-    return {"value": round(new_tokens / total, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            produced += 1
+        t_dec = time.time() - t0
+        total = time.time() - t_begin
+    return {"value": round(produced / total, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "images_per_sec": round(1.0 / total, 4),
-            "sample": (f"B=1: vision stack {t_vis:.2f}s + prefill T={prompt_len} {t_pre:.2f}s + {sample_tokens} decode steps "
-                       f"at {t_step:.3f}s/token, scaled to {new_tokens} tokens; fp32 oracle, weights unpacked in {t_unpack:.1f}s")}
+            "sample": (f"BASELINE configs[0] in full: 1 image, T={prompt_len} prompt, {produced} greedy tokens in {total:.1f}s "
+                       f"(vision stack {t_vis:.2f}s, prefill {t_pre:.2f}s, {produced - 1} decode steps {t_dec:.1f}s = {t_dec / max(produced - 1, 1):.3f}s/token); "
+                       f"fp32 oracle on {torch.get_num_threads()} of {os.cpu_count()} host threads, weights unpacked in {t_unpack:.1f}s (not timed)")}
+
+
+# ---------------------------------------------------------------------------------------------------------------- timing
+def timed_workload(step, steps: int, warmup: int, world: int, sync, barrier, allmax):
+    for _ in range(warmup):
+        step()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    return allmax(dt), out
+
+
+def plumbing_check(args, rank, world):
+    """The launch / shard / all-gather / max-over-ranks path with a stand-in for generate(): token (r, j) of global request r is
+    r * 1000 + j.  CPU, gloo.  Prints the same JSON skeleton; `value` is meaningless."""
+    import torch
+    import torch.distributed as dist
+    from visualcla.distributed import gather_tokens, shard_range
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    B, n_new = max(args.batch, 3), 8
+    gB = B * world
+    lo, hi = shard_range(gB, rank, world)
+
+    def step():
+        toks = (torch.arange(lo, hi)[:, None] * 1000 + torch.arange(n_new)[None, :]).to(torch.int64)
+        return gather_tokens(toks, n_total=gB, n_cols=n_new) if world > 1 else toks
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+
+    def allmax(dt):
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    dt, out = timed_workload(step, args.steps, args.warmup, world, lambda: None, barrier, allmax)
+    want = torch.arange(gB)[:, None] * 1000 + torch.arange(n_new)[None, :]
+    assert torch.equal(out, want), (rank, out, want)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check (no model)", "value": round(gB * n_new * args.steps / dt, 1), "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "config": {"workload": "token-pattern stand-in", "global_batch": gB, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.plumbing_check:
+        return plumbing_check(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -166,79 +335,98 @@ def main():
     if args.image_size != 224:
         model.set_image_size(args.image_size)
 
-    B = args.batch
-    gB = B * world
-    lo, hi = shard_range(gB, rank, world)
-    px, ids, mask = make_inputs(model.config, gB, args.prompt_len)      # same global batch on every rank; take my shard
-    px, ids, mask = px[lo:hi].to(dev, torch.bfloat16), ids[lo:hi].to(dev), mask[lo:hi].to(dev)
-    kw = dict(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=args.new_tokens, do_sample=False,
-              eos_token_id=None, use_graph=not args.no_graph)
-    if args.sample:   # models/visualcla/modeling_utils.py:36-47
-        kw.update(do_sample=True, top_p=0.9, top_k=40, temperature=0.5, repetition_penalty=1.1, no_repeat_ngram_size=15)
+    sync = torch.cuda.synchronize
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
 
-    def step():
-        toks = model.generate(**kw)
-        return gather_tokens(toks) if world > 1 else toks
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
+    def allmax(dt):
+        if world == 1:
+            return dt
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert out.shape == (gB, args.new_tokens), out.shape
+        return float(tt.item())
 
-    def timed(fn, reps=2):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
+    def run_workload(B, steps, warmup):
+        """B requests per GPU: every rank builds ONLY its shard of the global batch (request r is seeded by r, so a shard does
+        not depend on the world size), generate() + one all-gather of the ids per step"""
+        gB = B * world
+        lo, hi = shard_range(gB, rank, world)
+        px, ids, mask = make_inputs(model.config, hi - lo, args.prompt_len, first_request=lo)
+        px, ids, mask = px.to(dev, torch.bfloat16), ids.to(dev), mask.to(dev)
+        kw = dict(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=args.new_tokens, do_sample=False,
+                  eos_token_id=None, use_graph=not args.no_graph)
+        if args.sample:   # models/visualcla/modeling_utils.py:36-47
+            kw.update(do_sample=True, top_p=0.9, top_k=40, temperature=0.5, repetition_penalty=1.1, no_repeat_ngram_size=15)
 
-    breakdown = None
+        def step():
+            toks = model.generate(**kw)
+            return gather_tokens(toks, n_total=gB, n_cols=args.new_tokens) if world > 1 else toks
+        dt, out = timed_workload(step, steps, warmup, world, sync, barrier, allmax)
+        assert out.shape == (gB, args.new_tokens), out.shape
+        res = {"batch_per_gpu": B, "global_batch": gB, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
+               "tokens_per_sec": round(gB * args.new_tokens * steps / dt, 2), "images_per_sec": round(gB * steps / dt, 4)}
+        if rank == 0:   # stage split of one step (outside the timed region): vision stack, + splice/prefill/first token, + decode
+            def timed(fn, reps=2):
+                fn()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                sync()
+                return (time.perf_counter() - t0) / reps * 1e3
+            t_vis = timed(lambda: model.embed_images(px))
+            t_pre = timed(lambda: model.generate(**dict(kw, max_new_tokens=1)))
+            t_step = dt / steps * 1e3
+            res["breakdown_ms"] = {"vision_ms": round(t_vis, 2), "prefill_first_token_ms": round(t_pre - t_vis, 2),
+                                   "decode_ms": round(t_step - t_pre, 2),
+                                   "decode_ms_per_token_step": round((t_step - t_pre) / max(args.new_tokens - 1, 1), 3)}
+        return res
+
+    main_res = run_workload(args.batch, args.steps, args.warmup)
+    b64_res = None
+    if args.steps_b64 > 0 and args.batch == 1:
+        b64_res = run_workload(64, args.steps_b64, 1)
+
     if rank == 0:
-        # stage split of one step (outside the timed region): vision stack, + splice/prefill/first token, + decode
-        t_vis = timed(lambda: model.embed_images(px))
-        kw1 = dict(kw, max_new_tokens=1)
-        t_pre = timed(lambda: model.generate(**kw1))
-        breakdown = {"vision_ms": round(t_vis, 2), "prefill_first_token_ms": round(t_pre - t_vis, 2),
-                     "decode_ms": round(dt / args.steps * 1e3 - t_pre, 2),
-                     "decode_ms_per_token_step": round((dt / args.steps * 1e3 - t_pre) / max(args.new_tokens - 1, 1), 3)}
-
-    if rank == 0:
-        tokens = gB * args.new_tokens * args.steps
-        images = gB * args.steps
+        B = args.batch
+        cfgd = {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
+                             f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if args.sample else 'greedy'} decode "
+                             f"(BASELINE configs[{1 if B == 1 else 2}]); second workload config2 = the same at batch=64/GPU (BASELINE configs[2])"),
+                "global_batch": main_res["global_batch"], "seq_len": args.prompt_len, "new_tokens": args.new_tokens, "image_size": args.image_size,
+                "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"}
         res = {
             "metric": f"output tokens/sec ({'sampled' if args.sample else 'greedy'}, VisualCLA-7B {args.image_size}px; images/sec alongside)",
-            "value": round(tokens / dt, 2), "unit": "tokens/s",
-            "images_per_sec": round(images / dt, 4),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "value": main_res["tokens_per_sec"], "unit": "tokens/s",
+            # images/sec is the throughput figure of BASELINE configs[2] (B = 64 per GPU) when that workload ran, else the main workload's
+            "images_per_sec": (b64_res or main_res)["images_per_sec"],
+            "images_per_sec_workload": f"batch={(b64_res or main_res)['batch_per_gpu']}/GPU",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if not args.fp8 else "bf16 activations / fp32 accumulate, fp8-e4m3 decode weights", "data": "synthetic (random-init 7B weights, N(0,1) pixels, synthetic ids)",
-            "config": {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
-                                    f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if args.sample else 'greedy'} decode "
-                                    f"(BASELINE configs[{1 if B == 1 else 2}])"),
-                       "global_batch": gB, "seq_len": args.prompt_len, "new_tokens": args.new_tokens,
-                       "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"},
+            "dtype": "bf16" if not args.fp8 else "bf16 activations / fp32 accumulate, fp8-e4m3 decode weights",
+            "data": "synthetic (random-init 7B weights, N(0,1) pixels, synthetic ids)", "config": cfgd,
+            "breakdown_ms": main_res.get("breakdown_ms"),
         }
-        res["breakdown_ms"] = breakdown
-        res["roofline"] = gemv_roofline(model) if not args.fp8 else None
+        if b64_res:
+            res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
+        b1 = main_res if B == 1 else None
+        b64 = b64_res if b64_res else (main_res if B == 64 else None)
+        rl = []
+        if not args.fp8:
+            main_rl = gemv_roofline(model) if B == 1 else batch_decode_gemm_roofline(model, min(B, 64))
+            res["roofline"] = main_rl
+            rl.append(main_rl)
+            if B == 1 and b64:
+                r = batch_decode_gemm_roofline(model, 64)
+                if r:
+                    rl.append(r)
+            if args.image_size == 224:
+                rl.append(vit_gemm_roofline(model, 64))
+        else:
+            res["roofline"] = None
+        rl += step_rooflines(b1, b64, cfgd, args.fp8)
+        res["rooflines"] = rl
         if not args.no_cpu_baseline and world == 1 and args.image_size == 224:   # the CPU baseline is reported by the N=1 run only
             try:
-                res["cpu_baseline"] = cpu_baseline(model, args.prompt_len, args.new_tokens, args.cpu_tokens)
+                res["cpu_baseline"] = cpu_baseline(model, args.prompt_len, args.cpu_tokens)
             except Exception as e:  # e.g. host RAM too small for the 27 GB fp32 copy
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -104,6 +104,34 @@ def test_chat_matches_oracle_and_mutates_history(loaded, capsys):
     assert len(history) == 4 and isinstance(r2, str)
 
 
+def test_chat_stops_at_the_models_own_eos(loaded):
+    """The reference's DEFAULT_GENERATION_CONFIG leaves eos_token_id at None; HF's generate() then falls back on the model's own
+    generation config (text_encoder/generation_config.json or the ids in the LLaMA config.json).  chat() must stop there."""
+    from transformers import GenerationConfig
+    from visualcla.modeling_utils import encoding_text
+    visualcla, model, tokenizer, image_processor, cfg, W = loaded
+    img = _image()
+    enc = encoding_text([], "what is this?", model.num_patch, tokenizer)
+    px = image_processor(img, return_tensors="pt").pixel_values
+    want = O.visualcla_generate(enc.input_ids, px, enc.attention_mask, W, cfg, max_new_tokens=6)
+    eos = int(want[0, 2])
+    n_stop = int((want[0] == eos).nonzero()[0]) + 1                 # tokens up to and including the first eos
+    old = model.generation_config
+    try:
+        model.generation_config = GenerationConfig(eos_token_id=eos, pad_token_id=0)
+        gc = GenerationConfig(max_new_tokens=6, do_sample=False)      # eos_token_id None, as in the reference's default config
+        response, _ = visualcla.chat(model, img, "what is this?", history=[], generation_config=gc)
+        assert response == tokenizer.decode(want[0, :n_stop], skip_special_tokens=True)
+        pieces = list(visualcla.chat_in_stream(model, img, "what is this?", history=[], generation_config=gc))
+        assert len(pieces) == n_stop                               # the stream ends with the eos token too
+        # an explicit keyword still overrides (the benchmark disables the stop this way)
+        toks = model.generate(input_ids=enc.input_ids.cuda(), pixel_values=px.cuda(), attention_mask=enc.attention_mask.cuda(),
+                              generation_config=gc, eos_token_id=None)
+        assert toks.shape[1] == 6
+    finally:
+        model.generation_config = old
+
+
 def test_chat_in_stream_and_default_sampling(loaded):
     from transformers import GenerationConfig
     visualcla, model, tokenizer, image_processor, cfg, W = loaded

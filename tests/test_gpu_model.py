@@ -241,6 +241,7 @@ def model_7b():
     m.tokenizer = stub_tokenizer(ocfg)
     m.image_at_head = False
     yield m, ocfg
+    m._oracle_weights = None
     del m
     torch.cuda.empty_cache()
 
@@ -348,3 +349,168 @@ def test_7b_batch64_decode_matches_full_forward(model_7b, fp8):
         assert checked >= 16 and agree >= 0.9 * checked
     else:       # decode (panel kernels) and forward (256x256 tiles) round differently: allow the odd near-tie past the margin
         assert checked >= B and agree >= 0.98 * checked
+
+
+# ------------------------------------------------------------------ full VisualCLA-7B geometry: against the ORACLE (BASELINE shapes)
+# Stated bounds of the bf16 product path against the fp32 oracle at depth 24 (ViT) / 32 (LLaMA), random-init weights,
+# measured on MI355X (profiles/r02_parity_report.txt) and asserted with ~2x headroom:
+# measured: ViT taps grow from 0.7 % (layer 0) to 2.0 % (layer 23) of the tap's dynamic range, mean error 3e-3 -> 2.6e-2;
+# logits (std 1.29): max 0.45, mean 0.053 over 2 x 128 x 49958 values.  The same-dtype comparison below shows the reference
+# itself, run in bf16, sits at the same distance from its fp32 self.
+B7_VIT_REL = 4e-2        # every ViT / resampler tap: max |err| / max |ref|
+B7_LOGIT_MAX = 0.9       # logits: max abs error
+B7_LOGIT_MEAN = 0.1      # logits: mean abs error
+B7_MARGIN = 1.0          # top-2 margin of the fp32 reference beyond which the bf16 argmax must agree
+
+
+def _oracle_threads():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # one NUMA domain: torch's CPU kernels collapse on all SMT threads
+
+
+def _w7(m):
+    """the 7B weights as the oracle wants them (fp32 copies of the bf16-rounded values, ~27 GB of host RAM), unpacked once"""
+    if getattr(m, "_oracle_weights", None) is None:
+        m._oracle_weights = m.state_dict()
+    return m._oracle_weights
+
+
+def test_7b_vision_stack_matches_oracle_per_layer(model_7b):
+    """a3-a7 at the BASELINE shapes: all 24 ViT layer taps, post-LN, 6 resampler taps and the projected image embeds of a
+    B = 2 batch against the fp32 oracle on the same bf16-rounded weights"""
+    m, ocfg = model_7b
+    _oracle_threads()
+    px, _, _ = O.make_inputs(ocfg, 2, 128)
+    W = _w7(m)
+    ref_t = {}
+    with torch.no_grad():
+        O.image_embeds(px, W, ocfg, ref_t)
+    taps = {}
+    m.embed_images(px.cuda(), taps)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, ref in ref_t.items():
+        if k not in taps:
+            continue
+        got = taps[k].float().cpu().reshape(ref.shape)
+        err = (got - ref).abs()
+        rel = err.max().item() / max(ref.abs().max().item(), 1e-6)
+        worst = max(worst, rel)
+        _report(f"7B bf16 vs fp32 oracle {k}: max_abs_err={err.max().item():.3e} mean={err.mean().item():.3e} rel_to_absmax={rel:.3e}")
+        assert rel <= B7_VIT_REL, (k, rel)
+    assert len([k for k in ref_t if k in taps]) >= 24 + 1 + 6 + 1
+    _report(f"7B vision stack: worst tap error {worst:.3e} of the tap's dynamic range (bound {B7_VIT_REL})")
+
+
+def test_7b_prefill_and_decode_logits_match_oracle(model_7b):
+    """a1 / a2 / a8-a12 at the BASELINE shapes (configs[1] geometry, B = 2, T = 128): full-sequence forward logits, the
+    prefill's last-position logits and two KV-cache decode steps (teacher-forced with the HIP path's own tokens) against the
+    fp32 oracle; B = 2 runs the streaming batch-decode kernels, B = 1 the M = 1 GEMV path."""
+    from transformers import LogitsProcessorList
+    m, ocfg = model_7b
+    _oracle_threads()
+    B, T, n_new = 2, 128, 3
+    px, ids, mask = O.make_inputs(ocfg, B, T)
+    W = _w7(m)
+    with torch.no_grad():
+        img = O.image_embeds(px, W, ocfg)
+        x = O.embed_and_splice(ids, img, W, ocfg)
+        cache = [None] * ocfg.text.num_hidden_layers
+        h = O.llama_forward(x, W, ocfg.text, mask, cache, 0)
+        ref_all = O.lm_head(h, W)                                        # [B, T, V]
+    got_all = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
+    err = (got_all - ref_all).abs()
+    _report(f"7B forward logits [B={B},T={T}] vs fp32 oracle: max {err.max().item():.3e} mean {err.mean().item():.3e} (ref std {ref_all.std().item():.3f})")
+    assert err.max().item() <= B7_LOGIT_MAX and err.mean().item() <= B7_LOGIT_MEAN
+    top2 = ref_all.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > B7_MARGIN
+    agree = got_all.argmax(-1) == ref_all.argmax(-1)
+    assert bool(agree[decided].all())
+    _report(f"7B forward: argmax agrees at all {int(decided.sum())} positions whose fp32 top-2 margin exceeds {B7_MARGIN}, and at "
+            f"{int(agree.sum())} of {B * T} positions overall (random-init logits: median margin {float((top2[..., 0] - top2[..., 1]).median()):.3f})")
+    # SURVEY section 7 tolerance (ii) at the BASELINE shape: the reference arithmetic run in bf16 on the host (what the HF modules
+    # compute under .to(bfloat16)) against its own fp32 self, sample 0 -- the HIP path must not be further from fp32 than that
+    t0_ = __import__("time").time()
+    with torch.no_grad():
+        Wb = {k: v.to(torch.bfloat16) for k, v in W.items() if k.startswith("text_model.")}
+        hb = O.llama_forward(x[:1].to(torch.bfloat16), Wb, ocfg.text, mask[:1], None, 0)
+        hf_all = O.lm_head(hb, Wb).float()
+        del Wb
+    e_hf, e_hip = (hf_all - ref_all[:1]).abs(), (got_all[:1] - ref_all[:1]).abs()
+    _report(f"7B same-dtype (decoder, sample 0, T={T}): HIP-bf16 vs fp32 max {e_hip.max().item():.3e} mean {e_hip.mean().item():.3e} | "
+            f"oracle-in-bf16 vs fp32 max {e_hf.max().item():.3e} mean {e_hf.mean().item():.3e}  ({__import__('time').time() - t0_:.0f}s of host time)")
+    assert e_hip.mean().item() <= 1.5 * e_hf.mean().item() + 5e-3 and e_hip.max().item() <= 1.5 * e_hf.max().item() + 5e-2
+    for nb in (2, 1):
+        seen = []
+
+        def grab(ids_, scores):
+            seen.append(scores.detach().float().cpu().clone())
+            return scores
+        toks = m.generate(input_ids=ids[:nb].cuda(), pixel_values=px[:nb].cuda(), attention_mask=mask[:nb].cuda(), max_new_tokens=n_new,
+                          do_sample=False, eos_token_id=None, logits_processor=LogitsProcessorList([grab])).cpu()
+        with torch.no_grad():
+            cache = [None] * ocfg.text.num_hidden_layers
+            h = O.llama_forward(x[:nb], W, ocfg.text, mask[:nb], cache, 0)
+            refs = [O.lm_head(h[:, -1:], W)[:, 0]]
+            past = T
+            for s_ in range(n_new - 1):
+                e = W["text_model.model.embed_tokens.weight"][toks[:, s_]][:, None, :]
+                h = O.llama_forward(e, W, ocfg.text, torch.ones(nb, past + 1, dtype=torch.int64), cache, past)
+                refs.append(O.lm_head(h, W)[:, 0])
+                past += 1
+        for s_ in range(n_new):
+            e_ = (seen[s_] - refs[s_]).abs()
+            _report(f"7B B={nb} {'prefill' if s_ == 0 else f'decode step {s_}'} logits vs fp32 oracle: max {e_.max().item():.3e} mean {e_.mean().item():.3e}")
+            assert e_.max().item() <= B7_LOGIT_MAX and e_.mean().item() <= B7_LOGIT_MEAN, (nb, s_, e_.max().item())
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_bf16_path_is_no_worse_than_the_reference_run_in_bf16(name, golden_dir):
+    """SURVEY section 7, tolerance (ii): the product dtype against the SAME-dtype reference.  The oracle evaluated in bf16
+    (= what the HF modules do under .to(bfloat16)) has its own distance to the fp32 reference; the HIP path (bf16 storage,
+    fp32 accumulation) must not be further away than that (x1.5 + a small absolute floor), stage by stage and on the logits."""
+    g, cfg, W, px, ids, mask, n_new = _setup(name, golden_dir)
+    hf_t = {}
+    with torch.no_grad():
+        hf_logits = O.visualcla_forward(ids, px, mask, W, cfg, dtype=torch.bfloat16, taps=hf_t).float()
+    m = make_hip_model(cfg, W, torch.bfloat16)
+    taps = {}
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), taps=taps)
+    ref = torch.from_numpy(g["logits"])
+    e_hf, e_hip = (hf_logits - ref).abs(), (out.logits.float().cpu() - ref).abs()
+    _report(f"same-dtype {name} logits: HIP-bf16 max {e_hip.max().item():.3e} mean {e_hip.mean().item():.3e} | oracle-in-bf16 max {e_hf.max().item():.3e} mean {e_hf.mean().item():.3e}")
+    assert e_hip.max().item() <= 1.5 * e_hf.max().item() + 5e-3 and e_hip.mean().item() <= 1.5 * e_hf.mean().item() + 1e-3
+    for k in g.files:
+        if k.startswith("_") or k in ("generated", "vit_embed", "logits") or k not in hf_t or k not in taps:
+            continue
+        r = torch.from_numpy(g[k])
+        a_ = (hf_t[k].float().reshape(r.shape) - r).abs().mean().item()
+        b_ = (taps[k].float().cpu().reshape(r.shape) - r).abs().mean().item()
+        _report(f"same-dtype {name} {k}: HIP-bf16 mean err {b_:.3e} | oracle-in-bf16 {a_:.3e}")
+        assert b_ <= 1.5 * a_ + 1e-3 * max(r.abs().max().item(), 1.0), (k, b_, a_)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generate_on_a_left_padded_batch_matches_oracle(dtype):
+    """a batched chat(): sample 1 is left-padded; the reference (under the installed transformers) keeps arange positions and
+    masks the pad keys -- greedy ids must equal the oracle's in fp32 mode, and wherever the margin allows in bf16 mode"""
+    cfg = O.cfg_small()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 3, 48, n_prefix=6)
+    for b, npad in ((1, 4), (2, 1)):
+        ids[b] = torch.cat([torch.zeros(npad, dtype=ids.dtype), ids[b, :-npad]])
+        mask[b, :npad] = 0
+    n_new = 6
+    want, ref_logits = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=n_new, return_logits=True)
+    m = make_hip_model(cfg, W, dtype)
+    for use_graph in (False, True):
+        got = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=n_new, do_sample=False,
+                         eos_token_id=None, use_graph=use_graph).cpu()
+        if dtype == torch.float32:
+            assert torch.equal(got, want), (got, want)
+        else:
+            alive = torch.ones(3, dtype=torch.bool)
+            for s_ in range(n_new):
+                t2 = ref_logits[s_].topk(2, dim=-1).values
+                alive &= (t2[:, 0] - t2[:, 1]) > 0.12
+                assert bool((got[:, s_] == want[:, s_])[alive].all()), (s_, got, want)
+    _report(f"left-padded generate [{dtype}]: ids == oracle")

@@ -211,3 +211,29 @@ def test_streaming_path_uses_the_device_sampler_and_matches_the_graph_loop():
     host = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=g2, stopping_criteria=StoppingCriteriaList([Spy()]),
                           device_sampling=False)
     assert torch.equal(dev, host)
+
+
+def test_tie_run_beyond_the_kept_capacity_is_deterministic():
+    """More equal scores at the k-th value than the kept-set capacity (HF would keep them all): the kernel keeps every token
+    strictly above the tie and fills the rest of its 512 slots with the LOWEST tied token ids -- the same set on every run,
+    not whichever lanes won an atomic race"""
+    import dataclasses
+    cfg = dataclasses.replace(CFGS[0], repetition_penalty=1.0, no_repeat_ngram_size=0, top_k=40, top_p=1.0, temperature=1.0)
+    rng = np.random.default_rng(11)
+    B, V = 2, 49958
+    logits = (rng.standard_normal((B, V)) * 0.5 - 10.0).astype(np.float32)
+    above = rng.choice(V, size=7, replace=False)
+    tied = np.setdiff1d(rng.choice(V, size=900, replace=False), above)
+    logits[:, tied] = 3.0
+    logits[:, above] = 5.0 + np.arange(7, dtype=np.float32)
+    u = np.array([0.3, 0.9], dtype=np.float32)
+    hist = np.zeros((0, B), dtype=np.int64)
+    runs = [_run(logits.copy(), hist, cfg, u) for _ in range(3)]
+    out0, ids0, p0, n0 = runs[0]
+    cap = ids0.shape[1]
+    want = set(above.tolist()) | set(np.sort(tied)[: cap - len(above)].tolist())
+    for b in range(B):
+        assert int(n0[b]) == cap and set(ids0[b].tolist()) == want
+        assert abs(float(p0[b].sum()) - 1.0) < 1e-4 and int(out0[b]) in want
+    for out, ids, p, n in runs[1:]:
+        assert np.array_equal(out, out0) and np.array_equal(ids, ids0) and np.array_equal(n, n0)

@@ -1,5 +1,6 @@
 """CPU-side checks: the C-ABI library loads and exports every declared symbol, weight packing round-trips,
 prompt assembly follows the reference template, and the data-parallel shard/gather logic works on gloo (world 2)."""
+import json
 import os
 import re
 import subprocess
@@ -152,6 +153,12 @@ want = full.clone()
 lo1, hi1 = shard_range(n, 1, world)
 want[lo1:hi1, 2] = -1
 assert torch.equal(got, want), (rank, got, want)
+# the serving path: shapes known up front (n_total requests, max_new_tokens columns) -> ONE collective, no size exchange
+calls = []
+orig = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+got = gather_tokens(mine, n_total=n, n_cols=3, pad_id=-1)
+assert torch.equal(got, want) and len(calls) == 1, (rank, got, want, calls)
 dist.barrier()
 print("ok", rank)
 """
@@ -166,6 +173,32 @@ def test_data_parallel_gather_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_self_spawns_ranks_and_gathers_once():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself and report n_gpus = 2: the driver's
+    scaling command.  --plumbing-check runs exactly that launch / shard / all-gather / max-over-ranks path on CPU (gloo)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--plumbing-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 6
+
+
+def test_synthetic_shards_are_slices_of_the_global_batch():
+    """a rank builds only its own requests; they must be the same tensors a single process would slice out of the full batch"""
+    import visualcla
+    from visualcla.synthetic import make_inputs
+    cfg = visualcla.visualcla_7b_config()
+    cfg.vision_config = dict(cfg.vision_config, image_size=56)
+    px, ids, mask = make_inputs(cfg, 5, 128)
+    px2, ids2, mask2 = make_inputs(cfg, 2, 128, first_request=3)
+    assert torch.equal(px[3:5], px2) and torch.equal(ids[3:5], ids2) and torch.equal(mask[3:5], mask2)
 
 
 def test_python_constants_match_the_header():

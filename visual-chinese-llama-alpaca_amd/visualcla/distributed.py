@@ -5,7 +5,7 @@ all-gather of the generated token ids (KBs; latency-bound over xGMI).  `torch.di
 ROCm; the same code runs on "gloo" for the CPU tests."""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -20,13 +20,27 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_tokens(tokens: torch.Tensor, pad_id: int = 0) -> torch.Tensor:
-    """All-gather [b_rank, n] token ids from every rank into [sum b_rank, n_max] (rank order = request order).
-    Shards may be ragged in both dims (uneven split, early EOS): sizes are exchanged first, payloads are padded."""
+def gather_tokens(tokens: torch.Tensor, n_total: Optional[int] = None, n_cols: Optional[int] = None, pad_id: int = 0) -> torch.Tensor:
+    """All-gather [b_rank, n] token ids from every rank into [n_total, n_cols] (rank order = request order) with ONE collective.
+    The shard sizes follow from `shard_range(n_total, rank, world)` and every shard is padded to ceil(n_total / world) rows x
+    `n_cols` columns (= max_new_tokens; early EOS leaves pad_id behind), so nothing has to be exchanged up front and nothing
+    synchronises the host.  Without n_total / n_cols (ragged callers) the shapes are exchanged first: two collectives."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tokens
     world = dist.get_world_size()
     dev = tokens.device
+    if n_total is not None and n_cols is not None:
+        bmax = (n_total + world - 1) // world
+        if tokens.shape[0] > bmax or tokens.shape[1] > n_cols:
+            raise ValueError(f"shard {tuple(tokens.shape)} exceeds the padded shard shape ({bmax}, {n_cols})")
+        buf = torch.full((bmax, n_cols), pad_id, dtype=tokens.dtype, device=dev)
+        buf[: tokens.shape[0], : tokens.shape[1]] = tokens
+        out = torch.empty(world * bmax, n_cols, dtype=tokens.dtype, device=dev)
+        dist.all_gather_into_tensor(out, buf)
+        if n_total == world * bmax:
+            return out
+        sizes = [shard_range(n_total, r, world) for r in range(world)]
+        return torch.cat([out.view(world, bmax, n_cols)[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
     shape = torch.tensor(list(tokens.shape), dtype=torch.int64, device=dev)
     shapes = [torch.zeros_like(shape) for _ in range(world)]
     dist.all_gather(shapes, shape)
@@ -35,6 +49,6 @@ def gather_tokens(tokens: torch.Tensor, pad_id: int = 0) -> torch.Tensor:
     buf = torch.full((bmax, nmax), pad_id, dtype=tokens.dtype, device=dev)
     buf[: tokens.shape[0], : tokens.shape[1]] = tokens
     out = torch.empty(world * bmax, nmax, dtype=tokens.dtype, device=dev)
-    dist.all_gather_into_tensor(out, buf) if dev.type == "cuda" else dist.all_gather(list(out.view(world, bmax, nmax).unbind(0)), buf)
+    dist.all_gather_into_tensor(out, buf)
     parts = [out.view(world, bmax, nmax)[r, : int(shapes[r][0])] for r in range(world)]
     return torch.cat(parts, dim=0)

@@ -22,8 +22,10 @@ def stub_tokenizer(img_start: int = IMG_START_7B, img_end: int = IMG_END_7B, img
 
 def make_inputs(config, batch: int, seq_len: int, n_prefix: Optional[int] = None, image_size: Optional[int] = None,
                 img_ids=(IMG_START_7B, IMG_END_7B, IMG_TOKEN_7B), seed_pixels: int = 1,
-                seed_ids: int = 2) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """config: VisualCLAConfig.  -> (pixel_values [B,3,S,S] fp32 with bf16-representable values, input_ids [B,T], mask)"""
+                seed_ids: int = 2, first_request: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """config: VisualCLAConfig.  -> (pixel_values [B,3,S,S] fp32 with bf16-representable values, input_ids [B,T], mask).
+    `first_request`: return requests [first_request, first_request + batch) of the (unbounded) synthetic request stream -- a
+    data-parallel rank builds only its own shard; the earlier requests are drawn one at a time and dropped, never held."""
     v = config.vision_config
     Q = config.visual_resampler_config["num_query_tokens"]
     S = image_size or v["image_size"]
@@ -34,9 +36,14 @@ def make_inputs(config, batch: int, seq_len: int, n_prefix: Optional[int] = None
         raise ValueError(f"seq_len {seq_len} too short for {Q} image tokens")
     g1 = torch.Generator().manual_seed(seed_pixels)
     g2 = torch.Generator().manual_seed(seed_ids)
-    px = torch.randn(batch, v.get("num_channels", 3), S, S, generator=g1).to(torch.bfloat16).to(torch.float32)
+    C = v.get("num_channels", 3)
     start, end, tok = img_ids
     hi = min(img_ids)   # ordinary ids stay below the special ones
+    for _ in range(first_request):   # advance both streams past the other ranks' requests (C*S*S is a multiple of 16, the
+        torch.randn(1, C, S, S, generator=g1)   # block size of torch's CPU normal sampler: per-request draws == one big draw)
+        torch.randint(3, hi, (n_prefix,), generator=g2)
+        torch.randint(3, hi, (n_tail,), generator=g2)
+    px = torch.randn(batch, C, S, S, generator=g1).to(torch.bfloat16).to(torch.float32)
     rows = []
     for _ in range(batch):
         pre = torch.randint(3, hi, (n_prefix,), generator=g2)
