@@ -117,7 +117,8 @@ typedef struct vcla_gemm_args {
                              7 skinny MFMA (2 <= M <= 128, W streamed once, intra-workgroup split-K);
                              8 panel MFMA (M <= 128, activations shared through LDS, split-K over workgroups);
                              9 streaming MFMA (M <= 64, needs A_frag + W_frag / W_q8_frag: every CU streams an equal share of W over
-                               the FULL K, no split-K partials, no LDS in the main loop) */
+                               the FULL K, no split-K partials, no LDS in the main loop);
+                             10 fp8 MFMA 256x256x128 direct-to-LDS (needs A_q8 + a_scale + W_q8 + w_scale) */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */
@@ -162,6 +163,13 @@ typedef struct vcla_gemm_args {
     const float* a_row_ssq;
     int a_row_ssq_parts;
     float a_norm_eps;
+    /* fp8 x fp8 on the fp8 MFMA pipe (kernel 10, BASELINE configs[4]; the MI355X analogue of the reference's load_in_8bit,
+       models/visualcla/modeling_visualcla.py:155): A_q8 [M, K] OCP e4m3fn activations with one fp32 scale per row (a_scale [M],
+       A ~= A_q8 * a_scale[row]; vcla_quant_fp8_rows produces both) against W_q8 / w_scale.  The products run on
+       v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), fp32 accumulate; both row scales are applied in the epilogue.
+       K % 128 == 0, M > 0.  `A` is not read. */
+    const void* A_q8;
+    const float* a_scale;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */
@@ -172,6 +180,10 @@ int vcla_gemm(const vcla_gemm_args* args, int dtype, void* stream);
    vcla_rmsnorm.  gamma == NULL: plain re-layout (no normalisation).  cols % 32 == 0. */
 int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma, void* y_frag, int rows, int cols, float eps,
                       void* stream);
+
+/* Per-row dynamic fp8 quantisation of bf16 activations for the fp8 MFMA GEMM (vcla_gemm_args.A_q8 / a_scale):
+   scale[r] = max(|x[r, :]|) / 448 (>= 1e-20), q[r, c] = e4m3fn(x[r, c] / scale[r]) round-to-nearest-even.  cols % 16 == 0. */
+int vcla_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int rows, int cols, void* stream);
 
 /* Tuning harness (not used by the product path): the M = 1 bf16 GEMV with its streaming knobs exposed.
    variant = rows_per_wave | k_unroll << 8 | x_in_lds << 16 | nontemporal << 17 | waves_per_block << 20. */
@@ -287,6 +299,9 @@ typedef struct vcla_model_cfg {
     int t_hidden, t_layers, t_heads, t_inter, t_vocab, t_max_pos;
     float t_eps;
     float t_rope_theta;
+    /* 1: decoder GEMMs with more than 128 rows (prefill) whose weight has fp8 copies registered ("<name>.q8" + ".s8") run on the
+       fp8 MFMA pipe, activations quantised per row on the fly (BASELINE configs[4]); 0: bf16 MFMA */
+    int t_fp8_mfma;
 } vcla_model_cfg;
 
 typedef struct vcla_ctx vcla_ctx;

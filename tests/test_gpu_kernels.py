@@ -747,3 +747,74 @@ def test_gemm_dstream_deferred_rmsnorm(lib, M, D, N2, epi2):
     err = (got.float().cpu() - hf).abs()
     _report(f"deferred rmsnorm vs HF order [{M}x{N2}x{D},epi{epi2}]: max {err.max().item():.3e} mean {err.mean().item():.3e} (ref absmax {hf.abs().max().item():.2e})")
     assert err.max().item() <= 2e-2 * max(1.0, hf.abs().max().item())
+
+
+# ------------------------------------------------------------------ fp8 x fp8 on the fp8 MFMA pipe (kernel 10, BASELINE configs[4])
+@pytest.mark.parametrize("rows,cols", [(300, 4096), (7, 128), (129, 11008), (64, 1024)])
+def test_quant_fp8_rows_matches_torch(lib, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * torch.rand(rows, 1, generator=g) * 3).to(torch.bfloat16)
+    x[min(3, rows - 1)] = 0                                            # an all-zero row must not divide by zero
+    q, sc = lib.quant_fp8_rows(x.to(DEV))
+    torch.cuda.synchronize()
+    xf = x.float()
+    sc_ref = (xf.abs().amax(dim=1) / 448.0).clamp_min(1e-20)
+    assert torch.equal(sc.cpu(), sc_ref)
+    q_ref = (xf * (1.0 / sc_ref)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), q_ref)                                 # same scale, same round-to-nearest-even
+
+
+FP8_MFMA_SHAPES = [(300, 512, 256, 0), (1000, 1000, 1408, 1), (257, 384, 128, 2), (514, 2048, 1024, 3), (2 * 257, 4096, 1024, 1), (130, 320, 11008, 0)]
+
+
+@pytest.mark.parametrize("M,N,K,epi", FP8_MFMA_SHAPES)
+def test_gemm_fp8_mfma(lib, M, N, K, epi):
+    """kernel 10 computes exactly the function of the DEQUANTISED operands (e4m3 x e4m3 products are exact in fp32), fp32
+    accumulate, row scales applied in the epilogue; the distance to the unquantised product is reported"""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    wp = _pack(w)
+    wq, ws_ = quantize_fp8_rows(wp)
+    aq, as_ = lib.quant_fp8_rows(a.to(DEV, torch.bfloat16))
+    a_dq = dequantize_fp8_rows(aq, as_).cpu()
+    w_dq = dequantize_fp8_rows(wq, ws_)[:N].cpu()
+    ref = _gemm_ref(a_dq, w_dq, bias, epi, res)
+    got = lib.gemm(None, wp, N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi, force_kernel=10,
+                   a_q8=aq, a_scale=as_, w_q8=wq, w_scale=ws_)
+    _cmp(f"gemm_fp8_mfma[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-3, rtol=8e-3)
+    full = _gemm_ref(a, w, bias, epi, res)
+    err = (got.float().cpu() - full).abs()
+    _report(f"gemm_fp8_mfma[{M}x{N}x{K},epi{epi}] vs the unquantised product: max {err.max().item():.3e} mean {err.mean().item():.3e} (ref absmax {full.abs().max().item():.2e})")
+    if epi == 0:
+        got32 = lib.gemm(None, wp, N, out_f32=True, force_kernel=10, a_q8=aq, a_scale=as_, w_q8=wq, w_scale=ws_)
+        _cmp(f"gemm_fp8_mfma_f32[{M}x{N}x{K}]", got32, _gemm_ref(a_dq, w_dq, None, 0, None), atol=1e-3, rtol=2e-3)
+
+
+def test_gemm_fp8_mfma_identity_and_errors(lib):
+    """A = I (exactly representable) against an asymmetric W of exactly representable values: catches any operand-layout slip of
+    the 16x16x128 fragment (32 consecutive k per lane)"""
+    M, K, N = 300, 384, 333
+    a = torch.zeros(M, K)
+    a[torch.arange(M), (torch.arange(M) * 5) % K] = 1.0
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randint(-8, 9, (N, K), generator=g).float() / 8.0)     # multiples of 1/8 up to 1: exact in e4m3
+    wp = _pack(w)
+    from visualcla.weights import quantize_fp8_rows
+    wq = wp.float().to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    ones_w = torch.ones(wp.shape[0], device=DEV)
+    aq = a.to(DEV).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    ones_a = torch.ones(M, device=DEV)
+    got = lib.gemm(None, wp, N, out_f32=True, force_kernel=10, a_q8=aq, a_scale=ones_a, w_q8=wq, w_scale=ones_w)
+    _cmp("gemm_fp8_mfma_identity", got, a @ w.t(), atol=0.0)
+    with pytest.raises(ValueError):    # K must be a multiple of 128
+        lib.gemm(None, _pack(torch.randn(64, 192)), 64, force_kernel=10, a_q8=aq[:, :192].contiguous(), a_scale=ones_a,
+                 w_q8=wq[:128, :192].contiguous(), w_scale=ones_w)
+    with pytest.raises(ValueError):    # scales are mandatory
+        lib.gemm(None, wp, N, force_kernel=10, a_q8=aq, w_q8=wq, w_scale=ones_w)

@@ -514,3 +514,36 @@ def test_generate_on_a_left_padded_batch_matches_oracle(dtype):
                 alive &= (t2[:, 0] - t2[:, 1]) > 0.12
                 assert bool((got[:, s_] == want[:, s_])[alive].all()), (s_, got, want)
     _report(f"left-padded generate [{dtype}]: ids == oracle")
+
+
+def test_fp8_mfma_prefill_against_oracle_on_dequantised_weights(golden_dir):
+    """BASELINE configs[4]: with fp8 copies loaded, a prefill of more than 128 rows runs fp8 x fp8 on the fp8 MFMA pipe.  Against
+    the oracle on the DEQUANTISED weights the remaining error is the per-row activation quantisation (e4m3: 3 mantissa bits);
+    against the bf16-weight oracle it is weights + activations.  Stated bounds: max 0.25 / mean 0.03 on logits of std ~0.4."""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows, pad_to
+    g, cfg, W, px, ids, mask, n_new = _setup("small_b2", golden_dir)
+    B, T = 4, 48                                                        # 192 rows > 128 -> the MFMA tile kernels
+    px, ids, mask = O.make_inputs(cfg, B, T)
+    m = make_hip_model(cfg, W, torch.bfloat16)
+    base = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
+    m.enable_fp8_decode()                                               # prefill=True: fp8 MFMA for M > 128
+    got = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
+    assert not torch.equal(got, base)                                   # the fp8 path really ran
+    Wq = dict(W)
+    for k, v in W.items():
+        if k.startswith("text_model.model.layers.") and v.dim() == 2:
+            wp = torch.zeros(pad_to(v.shape[0], 128), v.shape[1])
+            wp[: v.shape[0]] = v
+            q, sc = quantize_fp8_rows(wp.to(torch.bfloat16))
+            Wq[k] = dequantize_fp8_rows(q, sc)[: v.shape[0]]
+    ref_q = O.visualcla_forward(ids, px, mask, Wq, cfg)
+    ref = O.visualcla_forward(ids, px, mask, W, cfg)
+    e_q, e_w = (got - ref_q).abs(), (got - ref).abs()
+    _report(f"fp8 MFMA prefill [B={B},T={T}] logits: vs oracle on dequantised weights max {e_q.max().item():.3e} mean {e_q.mean().item():.3e}; "
+            f"vs bf16-weight oracle max {e_w.max().item():.3e} mean {e_w.mean().item():.3e}; bf16 path vs oracle max {(base - ref).abs().max().item():.3e} (logit std {ref.std().item():.3f})")
+    assert e_q.max().item() <= 0.25 and e_q.mean().item() <= 0.03
+    toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=3, do_sample=False, eos_token_id=None)
+    assert toks.shape == (B, 3)
+    m.enable_fp8_decode(True, prefill=False)                            # decode-only fp8: prefill back on bf16 MFMA
+    again = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
+    assert torch.equal(again, base)

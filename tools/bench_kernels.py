@@ -235,6 +235,23 @@ def main():
             tp = timeit(lambda: _lib.rmsnorm_pack(xn, gam, 1e-6, out=pk), reps=50)
             print(f"M={M:3d} layer GEMMs: k8 (incl. reduce+norm launches) {tot['k8']*1e6:.1f} us | k9 {tot['k9']*1e6:.1f} us + 2 x rmsnorm_pack {tp*1e6:.1f} us"
                   f" = {(tot['k9'] + 2 * tp)*1e6:.1f} us ({404e6/(tot['k9'] + 2 * tp)/1e9:.0f} GB/s over 404 MB) || fp8: k8 {tot['k8q']*1e6:.1f} | k9 {tot['k9q']*1e6:.1f} us")
+    if "fp8mfma" in which:
+        # BASELINE configs[4]: the prefill / ViT GEMM shapes on the bf16 MFMA kernel (4) vs fp8 x fp8 on the fp8 MFMA pipe (10)
+        from visualcla.weights import quantize_fp8_rows
+        print("== bf16 256x256x64 (k4) vs fp8 256x256x128 (k10); TF/s against 2.5 PF (bf16) and 5 PF (fp8) dense peaks")
+        for tag, M, N, K, epi in (("llama qkv  B=64,T=128", 8192, 12288, 4096, 0), ("llama o", 8192, 4096, 4096, 0), ("llama gate-up", 8192, 22016, 4096, 3),
+                                  ("llama down", 8192, 4096, 11008, 0), ("llama qkv  B=32,T=128", 4096, 12288, 4096, 0),
+                                  ("vit fc1 B=64", 16448, 4096, 1024, 1), ("vit fc2 B=64", 16448, 1024, 4096, 0), ("vit qkv B=32 336px", 32 * 577, 3072, 1024, 0)):
+            a, w = rnd(M, K), packw(N, K)
+            out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+            t4 = timeit(lambda: _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=4), reps=10)
+            wq, ws_ = quantize_fp8_rows(w)
+            aq, as_ = _lib.quant_fp8_rows(a)
+            t10 = timeit(lambda: _lib.gemm(None, w, N, epilogue=epi, out=out, force_kernel=10, a_q8=aq, a_scale=as_, w_q8=wq, w_scale=ws_), reps=10)
+            tq = timeit(lambda: _lib.quant_fp8_rows(a), reps=10)
+            fl = 2.0 * M * N * K
+            print(f"{tag:24s} M={M:6d} N={N:6d} K={K:6d}  k4 {t4*1e6:8.1f} us {fl/t4/1e12:7.1f} TF/s ({fl/t4/2.5e13:.1f}%) | k10 {t10*1e6:8.1f} us {fl/t10/1e12:7.1f} TF/s "
+                  f"({fl/t10/5e13:.1f}% of 5 PF) | quantise A {tq*1e6:6.1f} us")
     if "panel" in which:
         print(f"== panel split-K kernel (fragment-major W), M=64, env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_PANEL")))
         skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)

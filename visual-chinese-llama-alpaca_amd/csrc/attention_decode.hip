@@ -244,15 +244,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         for (int e = 0; e < 8; ++e) part[wave * D + lane * 8 + e] = o[e];
     }
     __syncthreads();
-    if (tid < D) {
-        const float o_ = part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid];
-        if (out_frag_mt > 0) {
-            // fragment-major store for the streaming o_proj GEMM (vcla_gemm_args.A_frag): row b, column k = h*D + tid
-            const int k = h * D + tid;
-            Act<T>::st(out + ((((int64_t)(k >> 5) * out_frag_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7), o_);
-        } else {
-            Act<T>::st(out + (int64_t)b * HD + h * D + tid, o_);
+    if (out_frag_mt > 0) {
+        // fragment-major store for the streaming o_proj GEMM (vcla_gemm_args.A_frag): row b, columns k = h*D + 8 t .. + 7 are
+        // one 16-byte fragment slot -> D/8 threads, one 16-byte store each
+        if (tid < D / 8) {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = tid * 8 + e; o8[e] = part[c] + part[D + c] + part[2 * D + c] + part[3 * D + c]; }
+            const int k = h * D + tid * 8;
+            T* dst = out + ((((int64_t)(k >> 5) * out_frag_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3);
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(o8[0], o8[1]), pack_bf2(o8[2], o8[3]), pack_bf2(o8[4], o8[5]), pack_bf2(o8[6], o8[7]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Act<T>::st(dst + e, o8[e]);
+            }
         }
+    } else if (tid < D) {
+        Act<T>::st(out + (int64_t)b * HD + h * D + tid, part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]);
     }
 }
 

@@ -346,6 +346,8 @@ struct LlamaWs {
     int64_t* ids;
     void* splitk;
     float* ssq;     // [64][t_hidden / 16] per-row partial sums of squares (deferred RMSNorm of the streaming decode GEMMs)
+    void* q8;       // [M][max(t_hidden, t_inter)] fp8 copy of the activation operand (fp8 MFMA prefill, t_fp8_mfma)
+    float* q8s;     // [M] its per-row scales
 };
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -363,6 +365,11 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.ids = (int64_t*)b.take((size_t)B * 8);
     t.splitk = b.take(SPLITK_WS_BYTES);
     t.ssq = (float*)b.take((size_t)64 * ((c.t_hidden + 15) / 16) * 4);
+    t.q8 = nullptr; t.q8s = nullptr;
+    if (c.t_fp8_mfma && (size_t)B * T > 128) {
+        t.q8 = b.take(M * (size_t)(c.t_hidden > c.t_inter ? c.t_hidden : c.t_inter));
+        t.q8s = (float*)b.take(M * 4);
+    }
     if (w) *w = t;
     return b.off + 256;
 }
@@ -378,6 +385,8 @@ extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
 // ------------------------------------------------------------------ small wrappers
 static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry points from their workspace carve
 static thread_local bool g_decode_step = false;   // inside decode_step_impl: the fp8 weight copies (if loaded) may be used
+static thread_local void* g_q8_ws = nullptr;      // fp8 activation staging of the running prefill (t_fp8_mfma), else NULL
+static thread_local float* g_q8s_ws = nullptr;
 
 static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
@@ -392,6 +401,13 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.force_kernel = 0;
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
     a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
+    if (wv && wv->q8 && wv->s8 && g_q8_ws && M > 128 && K % 128 == 0 && lda == K && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0) {
+        // BASELINE configs[4]: prefill on the fp8 MFMA pipe -- quantise the activation rows (one pass over M x K), then fp8 x fp8
+        int rc = vcla_quant_fp8_rows(A, lda, g_q8_ws, g_q8s_ws, M, K, s);
+        if (rc) return rc;
+        a.A = nullptr; a.A_q8 = g_q8_ws; a.a_scale = g_q8s_ws; a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 10;
+        return vcla_gemm(&a, ctx->c.act_dtype, s);
+    }
     if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)
         // fp8 copies (when loaded) serve the DECODE steps only (g_decode_step; a short prefill keeps the bf16 values): half the HBM
         // bytes.  M = 1 GEMV: 1.3x end to end; panel kernel: 112 vs 132 us per layer at
@@ -607,6 +623,7 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     LlamaWs w;
     carve_llama(ctx, B, T, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     g_splitk_ws = w.splitk;
+    struct Q8Scope { Q8Scope(void* q, float* s_) { g_q8_ws = q; g_q8s_ws = s_; } ~Q8Scope() { g_q8_ws = nullptr; g_q8s_ws = nullptr; } } q8_scope(w.q8, w.q8s);
     VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < c.t_layers; ++l) {
         // every layer's down_proj also emits the next norm into w.h (the final norm only when all rows need it)

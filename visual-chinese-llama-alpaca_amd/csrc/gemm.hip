@@ -230,6 +230,98 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
     gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+
+// =================================================================== fp8 x fp8 MFMA kernel, 256x256x128 tile (kernel 10)
+// The same staging as gemm_mfma256_kernel -- a K tile of 128 fp8 values is 128 BYTES per row, exactly the row of a 64-wide bf16
+// tile, so the direct-to-LDS pieces, the source-side swizzle and the 128 KiB double buffer are unchanged -- but each lane now
+// carries 32 consecutive k (two 16-byte LDS reads) per operand tile and ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
+// scales) replaces two bf16 MFMA k-steps at twice the K: half the MFMA issue slots and half the LDS / HBM bytes per flop.
+// Per-row activation scales and per-row weight scales are applied to the fp32 accumulators in the epilogue.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_mfma256_fp8_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds8[];  // [buf][A|W][32 KiB]
+    int tm, tn;
+    tile_assign(blockIdx.x, tiles_m, tiles_n, 4, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const unsigned char* Ag = (const unsigned char*)a.A_q8;
+    const unsigned char* Wg = (const unsigned char*)a.W_q8;
+    const unsigned char* asrc[4];
+    const unsigned char* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (involution shared with lds_off)
+        int am = m0 + row, wr = n0 + row;
+        if (am >= a.M) am = a.M - 1;
+        if (wr >= n_pad) wr = n_pad - 1;
+        asrc[i] = Ag + (int64_t)am * a.K + chunk * 16;
+        wsrc[i] = Wg + (int64_t)wr * a.K + chunk * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* ab = lds8 + buf * 2 * G2_TILE_BYTES;
+        unsigned char* wb = ab + G2_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (int64_t)kt * 128), (lds_ptr_t)(ab + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[i] + (int64_t)kt * 128), (lds_ptr_t)(wb + piece * 1024), 16, 0, 0);
+        }
+    };
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = (lane >> 4) * 2;   // this lane's 32 k = 16-byte chunks fch, fch + 1 of the 128-byte row
+    const int nk = a.K / 128;
+    auto frag = [&](const unsigned char* base, int row) {
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(base + lds_off(row, fch));
+        const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(base + lds_off(row, fch + 1));
+        return i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // (compiler adds vmcnt(0)): tile kt has landed for every wave, and buffer cur^1 is no longer read
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const unsigned char* As = lds8 + cur * 2 * G2_TILE_BYTES;
+        const unsigned char* Ws = As + G2_TILE_BYTES;
+        i32x8_t wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = frag(Ws, wn * 64 + j * 16 + frow);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const i32x8_t af = frag(As, wm * 128 + i * 16 + frow);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af, acc[i][j], 0 /* A = fp8 e4m3 */, 0 /* B = fp8 e4m3 */,
+                                                                            0, 127 /* E8M0 1.0 */, 0, 127);
+        }
+    }
+    gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+template <int EPI, typename OutT>
+static int launch_mfma256_fp8(const vcla_gemm_args* a, hipStream_t s) {
+    const int tiles_m = (a->M + G2_BM - 1) / G2_BM, tiles_n = (a->N + G2_BN - 1) / G2_BN;
+    const int n_pad = (a->N + 127) / 128 * 128;
+    const size_t lds = 4 * G2_TILE_BYTES;  // 128 KiB
+    auto kern = gemm_mfma256_fp8_kernel<EPI, OutT>;
+    static bool attr_set = false;          // per instantiation
+    if (!attr_set) {
+        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    kern<<<tiles_m * tiles_n, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);
+    VCLA_CHECK_LAUNCH("gemm_mfma256_fp8_kernel");
+    return VCLA_OK;
+}
+
 // 16-byte non-temporal weight load: streamed-once data should not displace the L2-resident activations
 __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -1262,6 +1354,8 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
         return a->out_f32 ? launch_panel<EPI, float>(a, s) : launch_panel<EPI, bf16_t>(a, s);
     } else if (kernel == 9) {
         return vcla_gemm_dstream_launch(a, s);
+    } else if (kernel == 10) {
+        return a->out_f32 ? launch_mfma256_fp8<EPI, float>(a, s) : launch_mfma256_fp8<EPI, bf16_t>(a, s);
     } else if (kernel == 2 || kernel == 6) {
         if (kernel == 2 && gemv1_applicable(a, dtype)) return launch_gemv1_auto(a, s);
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
@@ -1293,7 +1387,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
     VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
-    VCLA_REQUIRE((a->A || a->A_frag) && a->W && (a->C || a->C_frag), VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE((a->A || a->A_frag || a->A_q8) && a->W && (a->C || a->C_frag), VCLA_ERR_BAD_ARG, "gemm: null pointer");
     VCLA_REQUIRE(a->epilogue >= VCLA_EPI_NONE && a->epilogue <= VCLA_EPI_SWIGLU, VCLA_ERR_BAD_ARG, "gemm: bad epilogue %d",
                  a->epilogue);
     VCLA_REQUIRE(a->epilogue != VCLA_EPI_SWIGLU || a->N % 32 == 0, VCLA_ERR_BAD_SHAPE,
@@ -1305,6 +1399,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     if (a->M == 0) return VCLA_OK;
     int kernel = a->force_kernel;
     if (kernel == 0 && a->A_frag) kernel = 9;   // fragment-major activations exist only for the streaming decode GEMM
+    if (kernel == 0 && a->A_q8) kernel = 10;    // fp8 activations exist only for the fp8 MFMA kernel
     if (kernel == 0) {
         if (dtype == VCLA_F32) kernel = a->M <= 8 ? 2 : 3;
         else if (a->M == 1 || (a->norm_gamma && a->M <= 8)) kernel = 2;   // GEMV (fused-norm capable)
@@ -1336,8 +1431,13 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             kernel = prefer_256(a) ? 4 : 1;
         }
     }
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 9, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
-    if (kernel == 9) {
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 10, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    if (kernel == 10) {
+        VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_q8 && a->a_scale && a->W_q8 && a->w_scale && vcla_aligned(a->A_q8, 16) && vcla_aligned(a->W_q8, 16) &&
+                         a->K % 128 == 0, VCLA_ERR_BAD_ARG, "gemm: the fp8 MFMA kernel needs A_q8 + a_scale, W_q8 + w_scale (16-byte aligned) and K %% 128 == 0 (K=%d)", a->K);
+        VCLA_REQUIRE(a->C && !a->C_frag && !a->A_frag && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
+                     "gemm: the fp8 MFMA kernel writes a row-major C and takes no fused norms");
+    } else if (kernel == 9) {
         VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_frag && vcla_aligned(a->A_frag, 16) && a->M <= 64 && (a->W_frag || a->W_q8_frag), VCLA_ERR_BAD_ARG,
                      "gemm: the streaming kernel needs bf16, A_frag, M <= 64 (got %d) and W_frag or W_q8_frag", a->M);
         VCLA_REQUIRE((a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && a->c_group_rows <= 0 && !a->norm_gamma &&
@@ -1349,8 +1449,8 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                      "gemm: c_row_ssq needs epilogue NONE, a bf16 output and N %% 16 == 0");
         VCLA_REQUIRE(!a->a_row_ssq || a->a_row_ssq_parts > 0, VCLA_ERR_BAD_ARG, "gemm: a_row_ssq needs a_row_ssq_parts > 0");
     } else {
-        VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
-                     "gemm: A_frag / C_frag / deferred-norm fields are implemented by the streaming kernel (9) only");
+        VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->A_q8 && !a->a_scale, VCLA_ERR_BAD_ARG,
+                     "gemm: A_frag / C_frag / deferred-norm fields belong to the streaming kernel (9), A_q8 / a_scale to the fp8 MFMA kernel (10)");
     }
     VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
@@ -1362,7 +1462,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights need w_scale and bf16 activations");
     VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
-    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9, VCLA_ERR_BAD_ARG,
+    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9 || kernel == 10, VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8) and the M <= 128 panel kernel (needs W_q8_frag)");
     VCLA_REQUIRE(!(kernel == 2 && a->w_scale) || (a->W_q8 && gemv1_applicable(a, dtype)), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 GEMV needs W_q8, M = 1, bf16, epilogue NONE/SWIGLU");

@@ -30,6 +30,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
         const int m = mw + i * 16 + mrow;
         if (m >= a.M) continue;
         const int64_t crow = remap_row(a, m);
+        const float ascale = a.a_scale ? a.a_scale[m] : 1.f;   // fp8 activations: per-row scale (kernel 10)
 #pragma unroll
         for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? NJ / 2 : NJ); ++j) {
             float v[4];
@@ -40,7 +41,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
-                    if (a.w_scale) { gt *= a.w_scale[np_ + r]; up *= a.w_scale[np_ + 16 + r]; }
+                    if (a.w_scale) { gt *= a.w_scale[np_ + r] * ascale; up *= a.w_scale[np_ + 16 + r] * ascale; }
                     if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
                     v[r] = act_silu(gt) * up;
                 }
@@ -49,7 +50,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[i][j][r];
-                    if (a.w_scale) x *= a.w_scale[n + r];   // n + r < N_pad always
+                    if (a.w_scale) x *= a.w_scale[n + r] * ascale;   // n + r < N_pad always
                     if (a.bias && n + r < a.N) x += a.bias[n + r];
                     v[r] = epi_act<EPI>(x);
                 }

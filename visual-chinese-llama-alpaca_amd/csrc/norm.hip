@@ -153,6 +153,47 @@ __global__ __launch_bounds__(256) void rmsnorm_pack_kernel(const bf16_t* __restr
     }
 }
 
+
+// Per-row dynamic fp8 (OCP e4m3fn) quantisation of bf16 activations for the fp8 MFMA GEMM: one WAVE per row for rows of up to
+// 16384 columns held in registers would cost 256 VGPRs; instead one 256-thread workgroup per row, the row staged once in LDS
+// as fp32 (one HBM read), absmax by shuffles, then 16 values -> one 16-byte store per thread.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, unsigned char* __restrict__ q,
+                                                             float* __restrict__ scale, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float qrow[];   // [cols]
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)r * ldx;
+    float mx = 0.f;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        float v[8];
+        bf8_to_f32(*reinterpret_cast<const uint4*>(xr + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qrow[c + e] = v[e]; mx = fmaxf(mx, fabsf(v[e])); }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = fmaxf(mx / 448.0f, 1e-20f);
+    const float inv = 1.0f / sc;
+    if (tid == 0) scale[r] = sc;
+    unsigned char* qr = q + (int64_t)r * cols;
+    for (int c = tid * 16; c < cols; c += 256 * 16) {
+        uint32_t w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(qrow[c + g * 4 + e] * inv, -448.0f), 448.0f);
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+            w[g] = (uint32_t)pk;
+        }
+        *reinterpret_cast<uint4*>(qr + c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // ViT input assembly: row (b, n): n == 0 -> class embedding, else patch embed (b, n-1); + position emb; pre-LN
 template <typename T>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ patch, const float* __restrict__ cls,
@@ -239,6 +280,17 @@ extern "C" int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma,
     const int v = vec4_ok(x, ldx, cols, VCLA_BF16);
     rmsnorm_pack_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, gamma, (bf16_t*)y_frag, cols, (rows + 15) / 16, eps, v);
     VCLA_CHECK_LAUNCH("rmsnorm_pack_kernel");
+    return VCLA_OK;
+}
+
+
+extern "C" int vcla_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int rows, int cols, void* stream) {
+    VCLA_REQUIRE(rows >= 0 && cols > 0 && cols % 16 == 0 && cols <= 16384 && ldx % 8 == 0, VCLA_ERR_BAD_SHAPE,
+                 "quant_fp8_rows: rows=%d cols=%d (multiple of 16, max 16384), ldx=%lld", rows, cols, (long long)ldx);
+    VCLA_REQUIRE(x && q && scale && vcla_aligned(x, 16) && vcla_aligned(q, 16), VCLA_ERR_BAD_ARG, "quant_fp8_rows: null / misaligned pointer");
+    if (rows == 0) return VCLA_OK;
+    quant_fp8_rows_kernel<<<rows, 256, (size_t)cols * 4, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (unsigned char*)q, scale, cols);
+    VCLA_CHECK_LAUNCH("quant_fp8_rows_kernel");
     return VCLA_OK;
 }
 

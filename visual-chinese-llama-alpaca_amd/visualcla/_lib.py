@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ("A_frag", C.c_void_p), ("C_frag", C.c_void_p),
         ("c_frag_gamma", C.c_void_p), ("c_row_ssq", C.c_void_p), ("a_row_ssq", C.c_void_p), ("a_row_ssq_parts", C.c_int),
         ("a_norm_eps", C.c_float),
+        ("A_q8", C.c_void_p), ("a_scale", C.c_void_p),
     ]
 
 
@@ -71,6 +72,7 @@ class ModelCfg(C.Structure):
         ("r_queries", C.c_int), ("r_eps", C.c_float),
         ("t_hidden", C.c_int), ("t_layers", C.c_int), ("t_heads", C.c_int), ("t_inter", C.c_int),
         ("t_vocab", C.c_int), ("t_max_pos", C.c_int), ("t_eps", C.c_float), ("t_rope_theta", C.c_float),
+        ("t_fp8_mfma", C.c_int),
     ]
 
 
@@ -111,6 +113,7 @@ SYMBOLS = {
     "vcla_rmsnorm": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     "vcla_gemm": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_rmsnorm_pack": (_i, [_vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
+    "vcla_quant_fp8_rows": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp]),
     "vcla_gemv_tune": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
@@ -236,14 +239,26 @@ def rmsnorm_pack(x, gamma, eps, out=None):
     return out
 
 
+def quant_fp8_rows(x):
+    """[M, K] bf16 -> (uint8 [M, K] e4m3fn bits, fp32 [M] per-row scale): the activation operand of the fp8 MFMA GEMM"""
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(load().vcla_quant_fp8_rows(ptr(x), x.stride(0), ptr(q), ptr(sc), M, K, stream_ptr()))
+    return q, sc
+
+
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
          group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None,
          post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None, a_frag=None, c_frag=None, m=None,
-         c_frag_gamma=None, c_row_ssq=None, a_row_ssq=None, a_norm_eps=0.0):
+         c_frag_gamma=None, c_row_ssq=None, a_row_ssq=None, a_norm_eps=0.0, a_q8=None, a_scale=None):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out].  a_frag ([K/32, MT, 64, 8], with m = M) selects
     the streaming decode kernel; c_frag (same layout over N_out) receives a fragment-major copy of the output."""
     lib = load()
-    if a is None:
+    if a is None and a_q8 is not None:
+        M, K = a_q8.shape
+        adt, adev = torch.bfloat16, a_q8.device
+    elif a is None:
         M, K = int(m), a_frag.shape[0] * 32
         adt, adev = torch.bfloat16, a_frag.device
     else:
@@ -256,6 +271,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args = GemmArgs()
     args.A, args.lda = ptr(a), (a.stride(0) if a is not None else 0)
     args.A_frag, args.C_frag = ptr(a_frag), ptr(c_frag)
+    args.A_q8, args.a_scale = ptr(a_q8), ptr(a_scale)
     args.c_frag_gamma, args.c_row_ssq, args.a_row_ssq = ptr(c_frag_gamma), ptr(c_row_ssq), ptr(a_row_ssq)
     args.a_row_ssq_parts, args.a_norm_eps = (a_row_ssq.shape[1] if a_row_ssq is not None else 0), float(a_norm_eps)
     args.W, args.bias = ptr(w_packed), ptr(bias)

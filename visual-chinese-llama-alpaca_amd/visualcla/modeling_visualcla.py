@@ -100,6 +100,7 @@ class VisualCLAModel:
         c.t_inter, c.t_vocab, c.t_max_pos = t["intermediate_size"], t["vocab_size"], t["max_position_embeddings"]
         c.t_eps = t.get("rms_norm_eps", 1e-6)
         c.t_rope_theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
+        c.t_fp8_mfma = int(bool(getattr(self, "_fp8_mfma", False)) and self._dtype == torch.bfloat16)
         if v.get("hidden_act", "quick_gelu") != "quick_gelu" or r.get("hidden_act", "gelu") != "gelu":
             raise ValueError("only quick_gelu (CLIP) and gelu (resampler) activations are implemented")
         return c
@@ -303,13 +304,22 @@ class VisualCLAModel:
                         self._build_ctx()
         return self
 
-    def enable_fp8_decode(self, enabled: bool = True):
+    def enable_fp8_decode(self, enabled: bool = True, prefill: bool = True):
         """BASELINE configs[4] weight path: OCP fp8 (e4m3fn, per-row scale) copies of the LLaMA projection / lm_head
-        matrices for the HBM-bound decode kernels (M <= 128); prefill tiles and the vision stack stay bf16.  The MI355X
-        analogue of the reference's `load_in_8bit` (bitsandbytes on the LLaMA only, modeling_visualcla.py:155)."""
+        matrices.  The HBM-bound decode kernels (M <= 128) stream them (half the bytes, dequantised in registers); with
+        `prefill` (default) the prefill GEMMs (M > 128) run fp8 x fp8 on the fp8 MFMA pipe
+        (v_mfma_scale_f32_16x16x128_f8f6f4), activations quantised per row on the fly.  The vision stack stays bf16.  The
+        MI355X analogue of the reference's `load_in_8bit` (bitsandbytes on the LLaMA only, modeling_visualcla.py:155)."""
         if self._dtype != torch.bfloat16:
             raise ValueError("fp8 decode weights need the bf16 activation mode")
         has = any(k.endswith(".q8") for k in self._packed)
+        want_mfma = bool(enabled and prefill)
+        if bool(getattr(self, "_fp8_mfma", False)) != want_mfma:
+            self._fp8_mfma = want_mfma
+            self._ws.clear()
+            if enabled == has:              # only the MFMA switch changed
+                self._build_ctx()
+                return self
         if enabled and not has:
             add_fp8_copies(self._packed)
         elif not enabled and has:
