@@ -170,6 +170,12 @@ typedef struct vcla_gemm_args {
        K % 128 == 0, M > 0.  `A` is not read. */
     const void* A_q8;
     const float* a_scale;
+    /* streaming kernel (9) only: split K into ds_splitk slices (0 / 1 = none).  Workgroups then own ds_splitk times as many
+       weight tiles over 1/ds_splitk of K -- each re-reads only that share of the activations (what bounds the short-N / long-K
+       GEMMs o_proj and down_proj at M = 64) -- store fp32 partial tiles in splitk_ws (>= ds_splitk * M * N * 4 bytes) and a
+       second, fully parallel launch sums the slices in order and applies the epilogue (bias, residual, C, C_frag, c_row_ssq).
+       Epilogue NONE only. */
+    int ds_splitk;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

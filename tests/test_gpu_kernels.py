@@ -818,3 +818,46 @@ def test_gemm_fp8_mfma_identity_and_errors(lib):
                  w_q8=wq[:128, :192].contiguous(), w_scale=ones_w)
     with pytest.raises(ValueError):    # scales are mandatory
         lib.gemm(None, wp, N, force_kernel=10, a_q8=aq, w_q8=wq, w_scale=ones_w)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,N,K,S", [(64, 4096, 4096, 4), (64, 4096, 11008, 4), (33, 1000, 1408, 2), (48, 2080, 2048, 8), (7, 320, 512, 3), (64, 4096, 4096, 16)])
+def test_gemm_dstream_splitk(lib, M, N, K, S, fp8):
+    """ds_splitk: S K slices per tile group, fp32 partial tiles in the workspace, a second launch sums them in slice order and runs
+    the epilogue (bias, residual in place, fragment-major copy x gamma, row sums of squares) -- same function as the unsplit
+    kernel, deterministic"""
+    from visualcla.weights import to_fragment_major, quantize_fp8_rows, dequantize_fp8_rows, to_fragment_pair_major_fp8
+    g = torch.Generator().manual_seed(M * 1000 + N + K + S)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    res = bf16r(torch.randn(M, N, generator=g))
+    gamma = bf16r(1 + 0.1 * torch.randn(N, generator=g))
+    wp = _pack(w)
+    kw = dict(w_frag=to_fragment_major(wp))
+    wref = w
+    if fp8:
+        q, sc = quantize_fp8_rows(wp)
+        wref = dequantize_fp8_rows(q, sc)[:N].cpu()
+        kw = dict(w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc)
+    ref = _gemm_ref(a, wref, bias, 0, res)
+    af = lib.to_frag(a.to(DEV, torch.bfloat16))
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    with_frag = N % 32 == 0
+    outs = []
+    for _ in range(2):
+        xd = res.to(DEV, torch.bfloat16)
+        cf = torch.zeros(N // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if with_frag else None
+        ssq = torch.zeros(M, N // 16, dtype=torch.float32, device=DEV) if N % 16 == 0 else None
+        lib.gemm(None, wp, N, bias=bias.to(DEV), residual=xd, out=xd, force_kernel=9, a_frag=af, m=M, splitk_ws=ws, ds_splitk=S,
+                 c_frag=cf, c_frag_gamma=gamma.to(DEV) if with_frag else None, c_row_ssq=ssq, **kw)
+        outs.append((xd, cf, ssq))
+    torch.cuda.synchronize()
+    xd, cf, ssq = outs[0]
+    _cmp(f"gemm_dstream_splitk[fp8={fp8},S{S},{M}x{N}x{K}]", xd, ref, atol=3e-3 if fp8 else 2e-3, rtol=8e-3)
+    x = xd.float().cpu()
+    if cf is not None:
+        assert torch.equal(lib.from_frag(cf, M).float().cpu(), bf16r(gamma * x))
+    if ssq is not None:
+        _cmp("gemm_dstream_splitk.ssq", ssq.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
+    assert torch.equal(outs[0][0], outs[1][0])

@@ -213,6 +213,17 @@ def main():
                     for w, wf in zip(ws, wfs):
                         _lib.gemm(None, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, force_kernel=9, a_frag=af, m=M, w_frag=wf)
                 t8, t9 = timeit(run8, reps=10) / nb, timeit(run9, reps=10) / nb
+                if res is not None:     # o / down: the split-K form of the streaming kernel (+ its reduce launch), as the engine runs it
+                    cfr = torch.zeros(n_out // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV)
+                    ssq = torch.zeros(M, n_out // 16, dtype=torch.float32, device=DEV)
+                    line = []
+                    for S_ in (1, 2, 4, 8):
+                        def run9s():
+                            for w, wf in zip(ws, wfs):
+                                _lib.gemm(None, w, N, out=out, residual=res, force_kernel=9, a_frag=af, m=M, w_frag=wf, splitk_ws=skws, ds_splitk=S_,
+                                          c_frag=cfr, c_frag_gamma=gam, c_row_ssq=ssq)
+                        line.append(f"S={S_} {timeit(run9s, reps=10) / nb * 1e6:6.1f} us")
+                    print(f"M={M:3d} {tag:8s} k9 with deferred-norm outputs, split-K: " + " | ".join(line))
                 qs = [quantize_fp8_rows(w) for w in ws]
                 qfs = [to_fragment_pair_major_fp8(q) for q, _ in qs]
                 def run8q():

@@ -421,8 +421,11 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
 // streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
 static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
                    void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0, const float* a_ssq = nullptr,
-                   int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr) {
+                   int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr, int splitk = 0) {
     vcla_gemm_args a{};
+    if (splitk > 1 && g_splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
+        a.ds_splitk = splitk; a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
+    }
     a.a_row_ssq = a_ssq; a.a_row_ssq_parts = a_parts; a.a_norm_eps = ctx->c.t_eps; a.c_frag_gamma = c_gamma; a.c_row_ssq = c_ssq;
     a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
@@ -546,6 +549,12 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         static const int defer_env = getenv("VCLA_DS_DEFER") ? atoi(getenv("VCLA_DS_DEFER")) : 1;
         const bool defer = defer_env != 0 && D % 16 == 0;
         const int parts = D / 16;
+        // o_proj / down_proj (N = 4096 outputs, 16 columns per workgroup) are bound by re-reading the activations (a CU ingests only
+        // ~45 GB/s from L2), not by the weights: K slices per tile group cut that traffic; a parallel reduce launch finishes the
+        // tiles.  Measured at M = 64 (tools/bench_kernels.py dstream): down_proj 33.2 -> 25.7 us with 4 slices, o_proj 15.7 -> 15.0
+        // with 2 (4: 15.8); at M = 32 only down_proj gains (24.4 -> 21.6 us).
+        static const int sk_env = getenv("VCLA_DS_SPLITK") ? atoi(getenv("VCLA_DS_SPLITK")) : 4;
+        const int sk_o = (M > 32 && D >= 2048 && sk_env > 1) ? 2 : 0, sk_d = (M > 16 && c.t_inter >= 4096) ? sk_env : 0;
         const float scale_ = 1.0f / sqrtf((float)d);
         if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
@@ -553,15 +562,15 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
                                    scale_, dt, /*out_frag=*/1, s));
         if (defer) {
-            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq));
+            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq, sk_o));
             RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, parts));
             RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, next_gamma ? w.h : nullptr, M, D, c.t_inter, VCLA_EPI_NONE, 0, nullptr, 0,
-                        next_gamma, next_gamma ? w.ssq : nullptr));
+                        next_gamma, next_gamma ? w.ssq : nullptr, sk_d));
         } else {
-            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, nullptr, M, D, D, VCLA_EPI_NONE));
+            RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, nullptr, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, nullptr, nullptr, sk_o));
             RUN(vcla_rmsnorm_pack(w.x, D, L.ln2g, w.h, M, D, c.t_eps, s));
             RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU));
-            RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, nullptr, M, D, c.t_inter, VCLA_EPI_NONE));
+            RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, nullptr, M, D, c.t_inter, VCLA_EPI_NONE, 0, nullptr, 0, nullptr, nullptr, sk_d));
         }
         return VCLA_OK;
     }

@@ -1448,6 +1448,10 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(!a->c_row_ssq || (a->epilogue == VCLA_EPI_NONE && !a->out_f32 && a->N % 16 == 0), VCLA_ERR_BAD_ARG,
                      "gemm: c_row_ssq needs epilogue NONE, a bf16 output and N %% 16 == 0");
         VCLA_REQUIRE(!a->a_row_ssq || a->a_row_ssq_parts > 0, VCLA_ERR_BAD_ARG, "gemm: a_row_ssq needs a_row_ssq_parts > 0");
+        VCLA_REQUIRE(a->ds_splitk <= 1 || (a->epilogue == VCLA_EPI_NONE && a->ds_splitk <= 16 && a->N % 4 == 0 && (a->ldc % 4 == 0 || !a->C) && a->splitk_ws &&
+                                           a->splitk_ws_bytes >= (size_t)a->ds_splitk * a->M * a->N * 4 && (!a->residual || a->ldr % 4 == 0) &&
+                                           (!a->c_row_ssq || a->N % 16 == 0) && a->K / (a->W_q8_frag ? 64 : 32) >= a->ds_splitk),
+                     VCLA_ERR_BAD_ARG, "gemm: ds_splitk needs epilogue NONE, N %% 4 == 0, 4-element aligned rows and a workspace of ds_splitk * M * N * 4 bytes");
     } else {
         VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->A_q8 && !a->a_scale, VCLA_ERR_BAD_ARG,
                      "gemm: A_frag / C_frag / deferred-norm fields belong to the streaming kernel (9), A_q8 / a_scale to the fp8 MFMA kernel (10)");

@@ -49,6 +49,11 @@ struct DsCtx {
     unsigned a_stage_bytes;   // A fragments of one stage: KS k-steps x MT tiles x 1 KiB
     unsigned w_tile_bytes;    // one 16-row weight tile over the full K
     int wave, lane, nst, mt_c;
+    int s_beg;                // first K stage of this workgroup's slice (split-K; 0 without)
+    int ks;                   // slice index, splitk slices in total
+    int splitk;
+    float* partial;           // [splitk][M][N] fp32 partial tiles (split-K only)
+    int M, N;
 };
 
 // deferred RMSNorm, consumer side: rstd of every activation row from the producer's per-tile sums of squares.  Called once per
@@ -99,7 +104,7 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
     // stage t of this wave = global stage ks = wave + 8 t
 #define DS_LOAD(s_, t_)                                                                                         \
     {                                                                                                           \
-        const unsigned ks_ = (unsigned)(c.wave + DS_WAVES * (t_));                                              \
+        const unsigned ks_ = (unsigned)(c.s_beg + c.wave + DS_WAVES * (t_));                                    \
         const unsigned ao_ = ks_ * c.a_stage_bytes, wo_ = w_chunk_off + (ks_ << 10);                            \
         _Pragma("unroll") for (int q = 0; q < KS; ++q)                                                          \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
@@ -186,12 +191,21 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
                     sum[0][tt][0] += p[0]; sum[0][tt][1] += p[1]; sum[0][tt][2] += p[2]; sum[0][tt][3] += p[3];
                 }
             const int jj = u / MT, i = u - jj * MT;
-            if (a.a_row_ssq) {   // deferred RMSNorm, consumer side: the lane's 4 values belong to row i*16 + (lane & 15)
-                const float rs = rstd_s[i * 16 + (c.lane & 15)];
+            if (c.splitk > 1) {
+                // split-K: the raw fp32 sums of this K slice go to the workspace; ds_reduce_kernel finishes the tile
+                if constexpr (TPU == 1) {
+                    const int m = i * 16 + (c.lane & 15), n = (c0 + jj) * 16 + (c.lane >> 4) * 4;
+                    if (m < c.M && n < c.N)      // N % 4 == 0 is checked on the host
+                        *reinterpret_cast<f32x4_t*>(c.partial + ((int64_t)c.ks * c.M + m) * c.N + n) = sum[0][0];
+                }
+            } else {
+                if (a.a_row_ssq) {   // deferred RMSNorm, consumer side: the lane's 4 values belong to row i*16 + (lane & 15)
+                    const float rs = rstd_s[i * 16 + (c.lane & 15)];
 #pragma unroll
-                for (int tt = 0; tt < TPU; ++tt) { sum[0][tt][0] *= rs; sum[0][tt][1] *= rs; sum[0][tt][2] *= rs; sum[0][tt][3] *= rs; }
+                    for (int tt = 0; tt < TPU; ++tt) { sum[0][tt][0] *= rs; sum[0][tt][1] *= rs; sum[0][tt][2] *= rs; sum[0][tt][3] *= rs; }
+                }
+                gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, c.lane);
             }
-            gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, c.lane);
         }
         __syncthreads();
     }
@@ -210,10 +224,14 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     DsCtx c;
     c.lane = threadIdx.x & 63;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int G = gridDim.x, g = blockIdx.x;
+    const int S = a.ds_splitk > 1 ? a.ds_splitk : 1;
+    const int G = gridDim.x / S, g = blockIdx.x / S;           // G groups of S workgroups: one K slice each, the same tiles
+    c.splitk = S; c.ks = blockIdx.x - g * S; c.partial = (float*)a.splitk_ws; c.M = a.M; c.N = a.N;
     const int t_beg = (int)((int64_t)g * units_total / G) * TPU, t_end = (int)((int64_t)(g + 1) * units_total / G) * TPU;
     const int KST = a.K / (32 * KS);                           // stages along K
-    c.nst = (KST - c.wave + DS_WAVES - 1) / DS_WAVES;          // stages of this wave
+    c.s_beg = (int)((int64_t)c.ks * KST / S);
+    const int s_len = (int)((int64_t)(c.ks + 1) * KST / S) - c.s_beg;
+    c.nst = (s_len - c.wave + DS_WAVES - 1) / DS_WAVES;        // stages of this wave inside the slice: s_beg + wave + 8 t
     c.mt_c = (a.M + 15) >> 4;                                  // == MT (the launcher instantiates MT = ceil(M/16))
     const int n_pad = (a.N + 127) / 128 * 128;
     c.w_tile_bytes = (unsigned)a.K * (FP8 ? 16u : 32u);
@@ -237,6 +255,61 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     }
 }
 
+
+// Second launch of a split-K streaming GEMM: out[m, n] = sum over the K slices (in slice order) of the fp32 partial tiles, then the
+// epilogue of the unsplit kernel: bias, residual, rounded store to C, optional fragment-major copy (x gamma) for the next
+// streaming GEMM and the per-row / per-16-column sums of squares of the deferred RMSNorm.  One thread per 4 consecutive columns
+// (16-byte partial loads, fully parallel over M x N / 4 threads).
+template <typename OutT>
+__global__ __launch_bounds__(256) void ds_reduce_kernel(vcla_gemm_args a, int splitk) {
+    const int n4 = a.N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < (int64_t)a.M * n4;
+    const int m = live ? (int)(idx / n4) : 0, n = live ? (int)(idx - (int64_t)m * n4) * 4 : 0;
+    const float* pp = (const float*)a.splitk_ws + (int64_t)m * a.N + n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (int s = 0; s < splitk; ++s) {
+            const float4 p = *reinterpret_cast<const float4*>(pp + (int64_t)s * a.M * a.N);
+            v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+        }
+        if (a.w_scale) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= a.w_scale[n + r];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += a.bias[n + r];
+        }
+        if (a.residual) {
+            float rv[4];
+            Act<bf16_t>::ld4((const bf16_t*)a.residual + (int64_t)m * a.ldr + n, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+    }
+    if (a.c_row_ssq) {   // the 4 threads of a 16-column tile are adjacent lanes (N % 16 == 0 -> a tile never straddles rows)
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = Act<OutT>::rnd(v[r]); q += live ? x * x : 0.f; }
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        if (live && (threadIdx.x & 3) == 0) a.c_row_ssq[(int64_t)m * (a.N >> 4) + (n >> 4)] = q;
+    }
+    if (!live) return;
+    if (a.C_frag) {
+        const int mt_c = (a.M + 15) >> 4;
+        bf16_t* fp = (bf16_t*)a.C_frag + ((((int64_t)(n >> 5) * mt_c + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7);
+        float f[4] = {v[0], v[1], v[2], v[3]};
+        if (a.c_frag_gamma) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = a.c_frag_gamma[n + r] * Act<OutT>::rnd(v[r]);
+        }
+        *reinterpret_cast<uint2*>(fp) = make_uint2(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]));
+    }
+    if (a.C) Act<OutT>::st4((OutT*)a.C + (int64_t)m * a.ldc + n, v);
+}
+
 template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
@@ -249,6 +322,13 @@ static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s
     }
     kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
     VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
+    if constexpr (EPI == VCLA_EPI_NONE) {
+        if (a->ds_splitk > 1) {
+            const int64_t work = (int64_t)a->M * (a->N / 4);
+            ds_reduce_kernel<OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
+            VCLA_CHECK_LAUNCH("ds_reduce_kernel");
+        }
+    }
     return VCLA_OK;
 }
 
@@ -268,7 +348,13 @@ int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
     const int tiles = (a->N + 15) / 16;                        // W_frag rows exist up to N_pad (multiple of 128) >= tiles * 16
     const int units = swiglu ? tiles / 2 : tiles;              // SwiGLU: N % 32 == 0
     static const int grid_env = getenv("VCLA_DS_GRID") ? atoi(getenv("VCLA_DS_GRID")) : 256;   // one workgroup per CU
-    const int grid = units < grid_env ? units : grid_env;
+    int grid = units < grid_env ? units : grid_env;
+    if (a->ds_splitk > 1) {   // groups of ds_splitk workgroups share a tile range: keep the launch at one workgroup per CU
+        int groups = grid_env / a->ds_splitk;
+        if (groups < 1) groups = 1;
+        if (groups > units) groups = units;
+        grid = groups * a->ds_splitk;
+    }
 #define DS_GO(EPI_, OUT_) return fp8 ? ds_pick_mt<EPI_, OUT_, true>(a, units, grid, s) : ds_pick_mt<EPI_, OUT_, false>(a, units, grid, s)
     if (swiglu) { DS_GO(VCLA_EPI_SWIGLU, bf16_t); }
     if (a->out_f32) { DS_GO(VCLA_EPI_NONE, float); }
