@@ -33,6 +33,7 @@
  *   vcla_vit_assemble       class/position embedding + pre_layrnorm hf:clip/modeling_clip.py:211-218,642
  *   vcla_attention          eager_attention_forward hf:clip/modeling_clip.py:259-277,
  *                           hf:llama/modeling_llama.py:191-214; modeling_visual_resampler.py:213-253
+ *   vcla_image_preprocess_batch   the same call sites, N same-sized images per launch pair
  *   vcla_image_preprocess   (next row N1) CLIPImageProcessor.__call__ as invoked at models/visualcla/modeling_utils.py:150-152
  *   vcla_embed_splice       embed_tokens + image splice modeling_visualcla.py:280,292-305 / :346,358-370
  *   vcla_rope_kv_append     apply_rotary_pos_emb + cache update hf:llama/modeling_llama.py:130-160,255-259
@@ -233,6 +234,14 @@ int vcla_image_preprocess(const uint8_t* img, int H, int W, uint8_t* tmp, int S,
                           const int32_t* h_k, int h_kmax, const int32_t* v_lo, const int32_t* v_cnt, const int32_t* v_k,
                           int v_kmax, double rescale, const float* mean3, const float* std3, void* out, int dtype,
                           void* stream);
+
+/* The same for N images of ONE size in one launch pair (imgs [N, H, W, 3] uint8, tmp N * H * S * 3 bytes, out [N, 3, S, S]): the
+   batched form a server feeds from one pinned staging buffer, so preprocessing costs two launches and one host-to-device copy
+   per BATCH instead of per image. */
+int vcla_image_preprocess_batch(const uint8_t* imgs, int N, int H, int W, uint8_t* tmp, int S, const int32_t* h_lo,
+                                const int32_t* h_cnt, const int32_t* h_k, int h_kmax, const int32_t* v_lo, const int32_t* v_cnt,
+                                const int32_t* v_k, int v_kmax, double rescale, const float* mean3, const float* std3, void* out,
+                                int dtype, void* stream);
 
 /* out[b, t] = table[ids[b, t]], except rows img_pos[b]+1 .. img_pos[b]+Q which take image_embeds[b, :]
    (img_pos[b] < 0: no image in that sample).  table is bf16 [V, D]. */

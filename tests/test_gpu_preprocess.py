@@ -63,3 +63,18 @@ def test_rejects_non_rgb_u8():
         proc(np.zeros((10, 10), np.uint8))
     with pytest.raises(ValueError):
         proc(np.zeros((10, 10, 3), np.float32))
+
+
+def test_batched_entry_is_bit_exact_and_keeps_input_order():
+    """vcla_image_preprocess_batch: N same-sized images in one launch pair; a mixed list is grouped by size and scattered back"""
+    from visualcla.preprocess import GpuClipImageProcessor
+    proc = GpuClipImageProcessor(size=224)
+    same = np.stack([_img((480, 640), s) for s in range(9)])
+    got = proc.preprocess_batch(torch.from_numpy(same).pin_memory())
+    assert got.shape == (9, 3, 224, 224)
+    for i in range(9):
+        assert np.array_equal(got[i].cpu().numpy(), P.clip_preprocess(same[i], 224))
+    mixed = [_img((480, 640), 1), _img((300, 400), 2), _img((480, 640), 3), _img((224, 224), 4), _img((300, 400), 5)]
+    got = proc(mixed).pixel_values
+    for i, im in enumerate(mixed):
+        assert np.array_equal(got[i].cpu().numpy(), P.clip_preprocess(im, 224)), i

@@ -97,30 +97,57 @@ class GpuClipImageProcessor:
             self._cache[key] = (dev, h_tab[2].shape[1], v_tab[2].shape[1])
         return self._cache[key]
 
-    def preprocess_into(self, image, out: torch.Tensor) -> None:
-        """image: PIL.Image or uint8 HWC array/tensor; out: [3, S, S] slice of the batch tensor (device, contiguous)."""
-        lib = _lib.load()
+    @staticmethod
+    def _as_uint8_hwc(image) -> torch.Tensor:
         if hasattr(image, "convert"):
             image = np.array(image.convert("RGB"))   # a writable copy: torch.as_tensor warns on PIL's read-only buffer
         img = torch.as_tensor(image)
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("expected a uint8 HWC RGB image")
-        img = img.to(self.device).contiguous()
-        H, W = int(img.shape[0]), int(img.shape[1])
+        return img
+
+    def preprocess_batch(self, images: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """images: uint8 [N, H, W, 3] (host -- ideally pinned -- or device) of ONE size -> [N, 3, S, S]: one host-to-device copy,
+        one launch pair (vcla_image_preprocess_batch), no per-image allocation."""
+        lib = _lib.load()
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError("expected a uint8 [N, H, W, 3] batch")
+        N, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
         S = self.size["shortest_edge"]
+        if out is None:
+            out = torch.empty(N, 3, S, S, dtype=self.dtype, device=self.device)
+        dev_imgs = images.to(self.device, non_blocking=True).contiguous()
         (h_lo, h_n, h_k, v_lo, v_n, v_k), hk, vk = self._plan(H, W)
-        tmp = torch.empty(H * S * 3, dtype=torch.uint8, device=self.device)
+        nbytes = N * H * S * 3
+        if getattr(self, "_tmp", None) is None or self._tmp.numel() < nbytes:
+            self._tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)     # grown, never shrunk: no per-call allocation
         mean = (C.c_float * 3)(*self.image_mean)
         std = (C.c_float * 3)(*self.image_std)
         with torch.cuda.device(self.device):
-            _lib.check(lib.vcla_image_preprocess(img.data_ptr(), H, W, tmp.data_ptr(), S, h_lo.data_ptr(), h_n.data_ptr(), h_k.data_ptr(),
-                                                 hk, v_lo.data_ptr(), v_n.data_ptr(), v_k.data_ptr(), vk, self.rescale_factor, mean, std,
-                                                 out.data_ptr(), _lib.dtype_code(out.dtype), _lib.stream_ptr()))
+            _lib.check(lib.vcla_image_preprocess_batch(dev_imgs.data_ptr(), N, H, W, self._tmp.data_ptr(), S, h_lo.data_ptr(), h_n.data_ptr(),
+                                                       h_k.data_ptr(), hk, v_lo.data_ptr(), v_n.data_ptr(), v_k.data_ptr(), vk,
+                                                       self.rescale_factor, mean, std, out.data_ptr(), _lib.dtype_code(out.dtype),
+                                                       _lib.stream_ptr()))
+        return out
+
+    def preprocess_into(self, image, out: torch.Tensor) -> None:
+        """image: PIL.Image or uint8 HWC array/tensor; out: [3, S, S] slice of the batch tensor (device, contiguous)."""
+        self.preprocess_batch(self._as_uint8_hwc(image)[None], out=out[None])
 
     def __call__(self, images, return_tensors="pt", **kwargs):
+        """CLIPImageProcessor's call: images of the same size are grouped into one staging buffer and one launch pair per group
+        (a batch of same-sized frames / thumbnails is ONE group); output order follows the input order."""
         imgs: List = list(images) if isinstance(images, (list, tuple)) else [images]
         S = self.size["shortest_edge"]
         out = torch.empty(len(imgs), 3, S, S, dtype=self.dtype, device=self.device)
-        for i, im in enumerate(imgs):
-            self.preprocess_into(im, out[i])
+        arrs = [self._as_uint8_hwc(im) for im in imgs]
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        for i, a in enumerate(arrs):
+            groups.setdefault((int(a.shape[0]), int(a.shape[1])), []).append(i)
+        for (H, W), idx in groups.items():
+            if len(idx) == len(imgs):                       # one size: preprocess straight into the output tensor
+                self.preprocess_batch(torch.stack(arrs) if len(idx) > 1 else arrs[0][None], out=out)
+            else:
+                res = self.preprocess_batch(torch.stack([arrs[i] for i in idx]))
+                out[torch.tensor(idx, device=self.device)] = res
         return SimpleNamespace(pixel_values=out)
