@@ -90,16 +90,16 @@ def _event_time(fn, reps: int):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the B = 1 gate/up GEMV from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    their own runs, FETCH_SIZE doubled per the gfx950 correction; tools/gpu_check.sh pmc).  Not collectable inside this run."""
+def _pmc_traffic(stem: str = "r01_pmc_gemv1"):
+    """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
+    runs, FETCH_SIZE doubled per the gfx950 correction; tools/gpu_check.sh pmc).  Not collectable inside this run."""
     import re
     try:
         tot = 0.0
         for nm in ("fetch_size", "write_size"):
-            m = re.search(r"-> ([0-9.]+) MB per launch", open(os.path.join(ROOT, "profiles", f"r01_pmc_gemv1_{nm}.txt")).read())
+            m = re.search(r"-> ([0-9.]+) MB per launch", open(os.path.join(ROOT, "profiles", f"{stem}_{nm}.txt")).read())
             tot += float(m.group(1)) * 1e6
-        return int(tot), "profiles/r01_pmc_gemv1_{fetch,write}_size.txt (separate rocprofv3 --pmc passes)"
+        return int(tot), f"profiles/{stem}_{{fetch,write}}_size.txt (separate rocprofv3 --pmc passes)"
     except Exception:
         return None, None
 
@@ -151,8 +151,9 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
                       w_frag=P[f"llama.l{l}.wgu.f"], c_frag=cf)
     sec = _event_time(run, n_rep) / L
     achieved = alg_bytes / sec / 1e9
+    traffic, src = _pmc_traffic("r02_pmc_dstream") if M == 64 else (None, None)
     return {"bound": "hbm", "kernel": f"gemm_dstream_kernel<SWIGLU,MT=4> (B={M} gate/up streaming GEMM, bf16)", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
 
 

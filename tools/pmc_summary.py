@@ -22,4 +22,4 @@ if counter not in ("FETCH_SIZE", "WRITE_SIZE"):
 mean_kib = sum(vals) / len(vals)
 corr = 2.0 if counter == "FETCH_SIZE" else 1.0
 print(f"{counter}: dispatches={len(vals)} mean={mean_kib:.1f} KiB raw -> {mean_kib * 1024 * corr / 1e6:.1f} MB per launch "
-      f"(x{corr:g} gfx950 correction); algorithmic = 180.4 MB weights + 8 KB x + 22 KB out")
+      f"(x{corr:g} gfx950 correction); algorithmic = 180.4 MB weights (+ KBs of activations / outputs)")
