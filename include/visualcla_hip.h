@@ -192,10 +192,6 @@ int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma, void* y_fr
    scale[r] = max(|x[r, :]|) / 448 (>= 1e-20), q[r, c] = e4m3fn(x[r, c] / scale[r]) round-to-nearest-even.  cols % 16 == 0. */
 int vcla_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int rows, int cols, void* stream);
 
-/* Tuning harness (not used by the product path): the M = 1 bf16 GEMV with its streaming knobs exposed.
-   variant = rows_per_wave | k_unroll << 8 | x_in_lds << 16 | nontemporal << 17 | waves_per_block << 20. */
-int vcla_gemv_tune(const vcla_gemm_args* args, int variant, void* stream);
-
 /* pixel_values [B, C, H, W] -> patches [B * (H/P) * (W/P), k_pad]; column order (c, ky, kx), zero padded */
 int vcla_im2col(const void* pixels, void* patches, int B, int C, int H, int W, int P, int k_pad, int dtype,
                 void* stream);

@@ -325,7 +325,7 @@ def test_7b_batch64_decode_matches_full_forward(model_7b, fp8):
     px, ids, mask = O.make_inputs(ocfg, B, T)
     px, ids, mask = px.cuda(), ids.cuda(), mask.cuda()
     if fp8:
-        m.enable_fp8_decode()
+        m.enable_fp8_decode(True, prefill=False)    # fp8 WEIGHTS in the decode kernels; the prefill that fills the cache stays bf16
     try:
         toks = m.generate(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=n_new, do_sample=False, eos_token_id=None)
     finally:
@@ -547,3 +547,29 @@ def test_fp8_mfma_prefill_against_oracle_on_dequantised_weights(golden_dir):
     m.enable_fp8_decode(True, prefill=False)                            # decode-only fp8: prefill back on bf16 MFMA
     again = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
     assert torch.equal(again, base)
+
+
+def test_7b_fp8_mfma_prefill_error_is_bounded(model_7b):
+    """BASELINE configs[4] at the 7B shape: the prefill on the fp8 MFMA pipe (e4m3 weights AND per-row-quantised e4m3 activations,
+    32 layers deep) against the bf16 prefill of the same model.  W8A8 with 3 mantissa bits is a lossy mode by construction: every
+    GEMM output carries ~5 % relative noise (3.6 % rms per operand), and a RANDOM-INIT 32-layer network amplifies any per-op
+    perturbation about 10x end to end (the bf16 path itself: 0.4 % per op -> 4 % of the logit spread, see the fp32-oracle test
+    above), so ~40-50 % is the expected figure here; measured: mean 0.38 x logit std, cosine 0.88.  Bounds with headroom; the
+    per-GEMM exactness (function of the dequantised operands) is pinned in tests/test_gpu_kernels.py::test_gemm_fp8_mfma."""
+    m, ocfg = model_7b
+    B, T = 2, 128
+    px, ids, mask = O.make_inputs(ocfg, B, T)
+    px, ids, mask = px.cuda(), ids.cuda(), mask.cuda()
+    base = m.forward(input_ids=ids, pixel_values=px, attention_mask=mask).logits.float()
+    m.enable_fp8_decode()                 # prefill=True
+    try:
+        got = m.forward(input_ids=ids, pixel_values=px, attention_mask=mask).logits.float()
+    finally:
+        m.enable_fp8_decode(False)
+    assert torch.isfinite(got).all() and not torch.equal(got, base)
+    err = (got - base).abs()
+    std = base.std().item()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), base.flatten(), dim=0).item()
+    _report(f"7B fp8 MFMA prefill vs bf16 prefill [B={B},T={T}]: logits max err {err.max().item():.3e} mean {err.mean().item():.3e} "
+            f"(logit std {std:.3f}, cosine {cos:.4f})")
+    assert err.mean().item() <= 0.55 * std and cos >= 0.8

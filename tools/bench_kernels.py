@@ -58,7 +58,13 @@ def bench_gemv_tune():
     """Every streaming variant on the real decode shapes, rotating over 8 weight buffers (> 256 MB MALL) so that the
     number is an HBM number, not an Infinity-Cache one."""
     import ctypes as C
-    lib = _lib.load()
+    tune_path = os.path.join(ROOT, "tools", "libvcla_tune.so")      # make -C visual-chinese-llama-alpaca_amd/csrc tune
+    if not os.path.exists(tune_path):
+        print("tools/libvcla_tune.so missing: run `make -C visual-chinese-llama-alpaca_amd/csrc tune` first")
+        return
+    lib = C.CDLL(tune_path)
+    lib.vcla_gemv_tune.restype, lib.vcla_gemv_tune.argtypes = C.c_int, [C.POINTER(_lib.GemmArgs), C.c_int, C.c_void_p]
+    lib.vcla_tune_last_error.restype = C.c_char_p
     shapes = [("qkv", 12288, 4096, 0, True), ("o", 4096, 4096, 0, False), ("gate-up", 22016, 4096, 3, True),
               ("down", 4096, 11008, 0, False)]
     NBUF = 8
@@ -94,7 +100,7 @@ def bench_gemv_tune():
                             for a in argsl:
                                 rc = lib.vcla_gemv_tune(C.byref(a), var, _lib.stream_ptr())
                                 if rc:
-                                    raise RuntimeError(lib.vcla_last_error().decode())
+                                    raise RuntimeError(lib.vcla_tune_last_error().decode())
                         try:
                             t = timeit(run, reps=5) / NBUF
                         except Exception as e:

@@ -2,7 +2,14 @@
 // gemv_kernel in gemm.hip with the streaming knobs exposed (rows per wave, k-loop unroll, x staged in LDS vs re-read
 // from L2, non-temporal weight loads, waves per workgroup), so one gpurun call can price every variant on the real
 // LLaMA-7B shapes.  Exported as vcla_gemv_tune(); the winning configuration is what gemm.hip hard-codes.
-#include "vcla_common.h"
+#include "vcla_common.h"   // built with -I visual-chinese-llama-alpaca_amd/csrc into tools/libvcla_tune.so (make -C .../csrc tune)
+
+// the harness is a stand-alone library: it carries its own copies of the two error helpers the product library defines in engine.hip
+#include <stdarg.h>
+static thread_local char t_err[512] = "";
+void vcla_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof(t_err), fmt, ap); va_end(ap); }
+int vcla_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof(t_err), fmt, ap); va_end(ap); return code; }
+extern "C" const char* vcla_tune_last_error(void) { return t_err; }
 
 __device__ __forceinline__ uint4 tune_ld(const bf16_t* p, bool nt) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

@@ -101,6 +101,8 @@ struct vcla_ctx {
     std::vector<VitLayer> vit;
     const void* res_query = nullptr;
     std::vector<ResLayer> res;
+    const void* res_wkv_all = nullptr;     // optional: K/V projections of all resampler layers stacked [L * 2D, D]
+    const float* res_bkv_all = nullptr;
     const void* proj_w = nullptr;
     const float* proj_b = nullptr;
     const void* embed = nullptr;
@@ -259,6 +261,15 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
         GET_W(L.w2, p + "w2", c.r_hidden, c.r_inter); GET_F(L.b2, p + "b2", c.r_hidden);
         GET_F(L.ln2g, p + "ln2.g", c.r_hidden); GET_F(L.ln2b, p + "ln2.b", c.r_hidden);
     }
+    {   // optional stacked K/V weights (no row padding between the layers: 2D % 128 == 0)
+        const void *wa = nullptr, *ba = nullptr;
+        int rc = get_tensor_opt(ctx, "res.wkv_all", (size_t)c.r_layers * 2 * c.r_hidden * c.r_hidden * 2, &wa);
+        if (!rc) rc = get_tensor_opt(ctx, "res.bkv_all", (size_t)c.r_layers * 2 * c.r_hidden * 4, &ba);
+        if (rc) return rc;
+        const bool ok = wa && ba && (2 * c.r_hidden) % 128 == 0;
+        ctx->res_wkv_all = ok ? wa : nullptr;
+        ctx->res_bkv_all = ok ? (const float*)ba : nullptr;
+    }
     GET_W(ctx->proj_w, "proj.w", c.t_hidden, c.r_hidden);
     GET_F(ctx->proj_b, "proj.b", c.t_hidden);
     if (c.t_layers == 0) {   // vision-only context
@@ -326,7 +337,7 @@ static size_t carve_vision(const vcla_ctx* ctx, int B, char* base, VisionWs* w) 
     t.mlp = b.take(B * N * c.v_inter * e);
     t.lat = b.take(B * Q * c.r_hidden * e);
     t.q = b.take(B * Q * c.r_hidden * e);
-    t.kv = b.take(B * (Q + N) * 2 * c.r_hidden * e);
+    t.kv = b.take(B * (Q + N) * 2 * c.r_hidden * e * (ctx->res_wkv_all ? c.r_layers : 1));   // [B, Q+N, L, 2D] when the image-row K/V are hoisted
     t.ao = b.take(B * Q * c.r_hidden * e);
     t.t = b.take(B * Q * c.r_hidden * e);
     t.h2 = b.take(B * Q * c.r_hidden * e);
@@ -499,16 +510,23 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
         VCLA_CHECK_LAUNCH("bcast_rows_kernel");
     }
     const int Mq = B * Q;
+    // K/V source of layer l = cat([latents_l, image tokens]) (modeling_visual_resampler.py:315): the image-token rows are the same
+    // in every layer, so their K/V for ALL layers come from one GEMM [B*N, D] x [D, L*2D] up front (stacked weights,
+    // res.wkv_all); layer l then only projects its 64 latent rows into its column block of the same [B, Q+N, L, 2D] buffer.
+    const bool hoist = ctx->res_wkv_all != nullptr;
+    const int kv_ld = hoist ? c.r_layers * 2 * Dr : 2 * Dr;          // row stride of the K/V buffer
+    if (hoist)
+        RUN(gemm(ctx, s, w.h, Dr, ctx->res_wkv_all, ctx->res_bkv_all, nullptr, 0, w.kv, kv_ld, M, c.r_layers * 2 * Dr, Dr, VCLA_EPI_NONE, 0, N, KV, Q));
     for (int l = 0; l < c.r_layers; ++l) {
         const ResLayer& L = ctx->res[l];
+        char* kvl = (char*)w.kv + (hoist ? (size_t)l * 2 * Dr * e : 0);
         RUN(gemm(ctx, s, w.lat, Dr, L.wq, L.bq, nullptr, 0, w.q, Dr, Mq, Dr, Dr, VCLA_EPI_NONE));
-        // K/V source = cat([latents, image tokens]) (modeling_visual_resampler.py:315): two GEMMs write the two row ranges
-        RUN(gemm(ctx, s, w.lat, Dr, L.wkv, L.bkv, nullptr, 0, w.kv, 2 * Dr, Mq, 2 * Dr, Dr, VCLA_EPI_NONE, 0, Q, KV, 0));
-        RUN(gemm(ctx, s, w.h, Dr, L.wkv, L.bkv, nullptr, 0, w.kv, 2 * Dr, M, 2 * Dr, Dr, VCLA_EPI_NONE, 0, N, KV, Q));
+        RUN(gemm(ctx, s, w.lat, Dr, L.wkv, L.bkv, nullptr, 0, kvl, kv_ld, Mq, 2 * Dr, Dr, VCLA_EPI_NONE, 0, Q, KV, 0));
+        if (!hoist) RUN(gemm(ctx, s, w.h, Dr, L.wkv, L.bkv, nullptr, 0, kvl, kv_ld, M, 2 * Dr, Dr, VCLA_EPI_NONE, 0, N, KV, Q));
         vcla_attn_args a{};
-        a.q = w.q; a.k = w.kv; a.v = (char*)w.kv + (size_t)Dr * e; a.o = w.ao;
+        a.q = w.q; a.k = kvl; a.v = kvl + (size_t)Dr * e; a.o = w.ao;
         a.q_bs = (int64_t)Q * Dr; a.q_hs = dr; a.q_rs = Dr;
-        a.k_bs = a.v_bs = (int64_t)KV * 2 * Dr; a.k_hs = a.v_hs = dr; a.k_rs = a.v_rs = 2 * Dr;
+        a.k_bs = a.v_bs = (int64_t)KV * kv_ld; a.k_hs = a.v_hs = dr; a.k_rs = a.v_rs = kv_ld;
         a.o_bs = (int64_t)Q * Dr; a.o_hs = dr; a.o_rs = Dr;
         a.B = B; a.H = Hr; a.Tq = Q; a.Tk = KV; a.D = dr; a.scale = 1.0f / sqrtf((float)dr); a.causal = 0;
         RUN(vcla_attention(&a, dt, s));

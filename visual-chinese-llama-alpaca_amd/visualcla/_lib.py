@@ -115,7 +115,6 @@ SYMBOLS = {
     "vcla_gemm": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_rmsnorm_pack": (_i, [_vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
     "vcla_quant_fp8_rows": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp]),
-    "vcla_gemv_tune": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "vcla_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "vcla_attention": (_i, [C.POINTER(AttnArgs), _i, _vp]),

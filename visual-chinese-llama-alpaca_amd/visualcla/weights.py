@@ -92,6 +92,24 @@ def add_fp8_copies(packed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return packed
 
 
+def add_resampler_kv_all(packed: Dict[str, torch.Tensor], n_layers: int) -> Dict[str, torch.Tensor]:
+    """`res.wkv_all` [L * 2D, D] / `res.bkv_all` [L * 2D]: the K/V projections of ALL resampler layers stacked, so that the
+    image-token rows -- which do not depend on the latents (modeling_visual_resampler.py:315-316 projects cat([latents, image])
+    with the same Linear in every layer) -- go through ONE GEMM [B*N, D] x [D, L*2D] before the layer loop instead of one per
+    layer.  The per-layer tensors become views of the stacked one (no second copy).  Needs 2D % 128 == 0 (no row padding
+    between the layers); otherwise nothing is added and the engine keeps the per-layer GEMMs."""
+    ws = [packed[f"res.l{i}.wkv"] for i in range(n_layers)]
+    bs = [packed[f"res.l{i}.bkv"] for i in range(n_layers)]
+    if n_layers == 0 or ws[0].shape[0] != bs[0].shape[0]:      # rows were padded to a multiple of 128
+        return packed
+    wall, ball = torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
+    n = ws[0].shape[0]
+    packed["res.wkv_all"], packed["res.bkv_all"] = wall, ball
+    for i in range(n_layers):
+        packed[f"res.l{i}.wkv"], packed[f"res.l{i}.bkv"] = wall[i * n:(i + 1) * n], ball[i * n:(i + 1) * n]
+    return packed
+
+
 FRAG_KEYS = ("wqkv", "wo", "wgu", "wd")     # LLaMA decode matrices that get a fragment-major twin (".f")
 
 
@@ -250,6 +268,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg, device, act_dtype: torch.d
         out[d + "ln2.b"] = _f32(g(s + "output.LayerNorm.bias"), device)
     out["proj.w"] = _pack_w(g("image_projection_layer.weight"), device)
     out["proj.b"] = _f32(g("image_projection_layer.bias"), device)
+    add_resampler_kv_all(out, r["num_hidden_layers"])
 
     if t.get("num_hidden_layers", 0) == 0:       # vision-only context (tgwebui pipeline): no decoder tensors
         return out
@@ -321,6 +340,7 @@ def random_packed(cfg, device, act_dtype: torch.dtype, seed: int = 0) -> Dict[st
         out[d + "ln2.g"], out[d + "ln2.b"] = vec(Dr, 1.0, 0.1), vec(Dr)
     Dt, It, V = t["hidden_size"], t["intermediate_size"], t["vocab_size"]
     out["proj.w"], out["proj.b"] = w(Dt, Dr), vec(Dt)
+    add_resampler_kv_all(out, r["num_hidden_layers"])
     out["llama.embed"] = (torch.randn(V, Dt, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
     for i in range(t["num_hidden_layers"]):
         d = f"llama.l{i}."
