@@ -25,6 +25,78 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
     const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a.N / 2 : a.N;
     const bool vec_c = Cg && (a.ldc % 4 == 0) && vcla_aligned_dev(Cg, kF32 ? 16 : 8);
     const bool vec_r = a.residual && (a.ldr % 4 == 0) && vcla_aligned_dev(a.residual, 8);
+    // values of output tile jo (0 .. NOUT-1) of row tile i for this lane: bias / fp8 scales / activation / residual applied;
+    // returns the first of the lane's 4 output columns
+    constexpr int NOUT = (EPI == VCLA_EPI_SWIGLU) ? NJ / 2 : NJ;
+    auto tile_vals = [&](int i, int jo, int m, float ascale, float (&v)[4]) -> int {
+        int n;
+        if constexpr (EPI == VCLA_EPI_SWIGLU) {
+            n = nw / 2 + jo * 16 + nq;
+            const int np_ = nw + (2 * jo) * 16 + nq;  // packed column of the gate values (bias index)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gt = acc[i][2 * jo][r], up = acc[i][2 * jo + 1][r];
+                if (a.w_scale) { gt *= a.w_scale[np_ + r] * ascale; up *= a.w_scale[np_ + 16 + r] * ascale; }
+                if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
+                v[r] = act_silu(gt) * up;
+            }
+        } else {
+            n = nw + jo * 16 + nq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][jo][r];
+                if (a.w_scale) x *= a.w_scale[n + r] * ascale;   // n + r < N_pad always
+                if (a.bias && n + r < a.N) x += a.bias[n + r];
+                v[r] = epi_act<EPI>(x);
+            }
+        }
+        if (a.residual && n < n_out) {
+            const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
+            if (vec_r && n + 3 < n_out) {
+                float rv[4];
+                Act<bf16_t>::ld4(rp, rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out) v[r] += bf2f(rp[r]);
+            }
+        }
+        return n;
+    };
+    // ---- wide stores (bf16 output, plain row-major C): the epilogue of a 256 x 256 tile is store-ISSUE bound (32 eight-byte
+    // stores per lane).  Two adjacent output tiles are exchanged between the lane rows with v_permlane16_swap (rows 1 / 3 of the
+    // first tile's registers <-> rows 0 / 2 of the second's): afterwards lane row r holds 8 CONSECUTIVE columns of tile
+    // j + (r & 1), starting at column (r >> 1) * 8 -> one 16-byte store instead of two 8-byte ones.
+    if constexpr (!kF32 && NOUT % 2 == 0) {
+        const int n_first = (EPI == VCLA_EPI_SWIGLU) ? nw / 2 : nw;
+        const bool wide = Cg && !a.C_frag && !a.c_row_ssq && (a.ldc % 8 == 0) && vcla_aligned_dev(Cg, 16) && (n_first % 8 == 0) &&
+                          n_first + NOUT * 16 <= n_out;        // wave-uniform: the whole tile row is inside the matrix
+        if (wide) {
+            const int row_ = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mw + i * 16 + mrow;
+                if (m >= a.M) continue;                        // the 4 lanes that exchange data share m
+                const int64_t crow = remap_row(a, m);
+                const float ascale = a.a_scale ? a.a_scale[m] : 1.f;
+#pragma unroll
+                for (int p = 0; p < NOUT / 2; ++p) {
+                    float v0[4], v1[4];
+                    tile_vals(i, 2 * p, m, ascale, v0);
+                    tile_vals(i, 2 * p + 1, m, ascale, v1);
+                    unsigned a0 = pack_bf2(v0[0], v0[1]), a1 = pack_bf2(v0[2], v0[3]);
+                    unsigned b0 = pack_bf2(v1[0], v1[1]), b1 = pack_bf2(v1[2], v1[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    const int n = n_first + (2 * p + (row_ & 1)) * 16 + (row_ >> 1) * 8;
+                    *reinterpret_cast<uint4*>(Cg + crow * a.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw + i * 16 + mrow;
@@ -32,43 +104,10 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
         const int64_t crow = remap_row(a, m);
         const float ascale = a.a_scale ? a.a_scale[m] : 1.f;   // fp8 activations: per-row scale (kernel 10)
 #pragma unroll
-        for (int j = 0; j < (EPI == VCLA_EPI_SWIGLU ? NJ / 2 : NJ); ++j) {
+        for (int j = 0; j < NOUT; ++j) {
             float v[4];
-            int n;  // first output column of this lane's 4
-            if constexpr (EPI == VCLA_EPI_SWIGLU) {
-                n = nw / 2 + j * 16 + nq;
-                const int np_ = nw + (2 * j) * 16 + nq;  // packed column of the gate values (bias index)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = acc[i][2 * j][r], up = acc[i][2 * j + 1][r];
-                    if (a.w_scale) { gt *= a.w_scale[np_ + r] * ascale; up *= a.w_scale[np_ + 16 + r] * ascale; }
-                    if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
-                    v[r] = act_silu(gt) * up;
-                }
-            } else {
-                n = nw + j * 16 + nq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r];
-                    if (a.w_scale) x *= a.w_scale[n + r] * ascale;   // n + r < N_pad always
-                    if (a.bias && n + r < a.N) x += a.bias[n + r];
-                    v[r] = epi_act<EPI>(x);
-                }
-            }
+            const int n = tile_vals(i, j, m, ascale, v);   // first output column of this lane's 4
             if (n >= n_out) continue;
-            if (a.residual) {
-                const bf16_t* rp = (const bf16_t*)a.residual + (int64_t)m * a.ldr + n;
-                if (vec_r && n + 3 < n_out) {
-                    float rv[4];
-                    Act<bf16_t>::ld4(rp, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < n_out) v[r] += bf2f(rp[r]);
-                }
-            }
             if (a.c_row_ssq) {
                 // deferred RMSNorm, producer side: sum of squares of the ROUNDED values of this row over this 16-column tile
                 // (the 4 lanes l, l+16, l+32, l+48 hold the row's 16 columns); host guarantees N % 16 == 0 here
@@ -103,4 +142,3 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
         }
     }
 }
-
