@@ -467,6 +467,28 @@ def test_gemv1_f32_out_bias_residual(lib):
         _cmp(f"gemv1_full[k{fk}]", got, ref, atol=2e-4, rtol=1e-5)
 
 
+# ------------------------------------------------------------------ compile-time-K decode GEMV (gemv_decode.hip)
+@pytest.mark.parametrize("N,K,epi,f32out", [(4096, 4096, 0, False), (12288, 4096, 0, False), (22016, 4096, 3, False), (4096, 11008, 0, False),
+                                            (49958, 4096, 0, True), (1000, 4096, 0, False), (5120, 5120, 0, False), (27648, 5120, 3, False),
+                                            (5120, 13824, 0, False), (331, 11008, 0, True)])
+def test_gemv1x_llama_widths(lib, N, K, epi, f32out):
+    """M = 1 at the LLaMA-7B / 13B widths (the instances of gemv1x_kernel): fused RMSNorm, bias, residual, SwiGLU, fp32 logits,
+    N that is not a multiple of the 8 rows of a workgroup, the ragged last k-step of K = 11008 / 13824"""
+    g = torch.Generator().manual_seed(N + K + epi)
+    x = bf16r(torch.randn(1, K, generator=g) * 1.3)
+    gamma = bf16r(1 + 0.1 * torch.randn(K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.03)
+    n_out = N // 2 if epi == 3 else N
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    res = bf16r(torch.randn(1, n_out, generator=g))
+    for use_norm in (True, False):
+        h = O.llama_rmsnorm(x, gamma, 1e-6) if use_norm else x
+        ref = _gemm_ref(h, w, bias, epi, res)
+        got = lib.gemm(x.to(DEV, torch.bfloat16), _pack(w), N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi,
+                       out_f32=f32out, norm_gamma=gamma.to(DEV) if use_norm else None, norm_eps=1e-6)
+        _cmp(f"gemv1x[{N}x{K},epi{epi},norm{int(use_norm)}]", got, ref, atol=2e-4 if f32out else 4e-3, rtol=1e-5 if f32out else 8e-3)
+
+
 # ------------------------------------------------------------------ fp8 (e4m3fn) decode weights
 @pytest.mark.parametrize("M,N,K,epi", [(1, 4096, 512, 0), (1, 2048, 1408, 3), (1, 1000, 4096, 0), (2, 512, 4096, 0), (16, 4096, 1408, 3),
                                        (64, 320, 640, 0), (128, 288, 2048, 3)])

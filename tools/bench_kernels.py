@@ -188,6 +188,26 @@ def main():
                     t = timeit(run, reps=10) / 4
                     print(f"k{fk}{'f' if frag else ' '} {tag:8s} M={M:4d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:8.1f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
                 del ws, wfs
+    if "gemv1" in which:
+        # B = 1 decode GEMVs, rotating over 6 weight buffers (HBM figures); VCLA_GEMV1X=0 selects the runtime-K kernel
+        print("== M = 1 decode GEMVs; env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_")))
+        tot = 0.0
+        for tag, N, K, epi, norm, f32 in (("qkv", 12288, 4096, 0, True, False), ("o", 4096, 4096, 0, False, False), ("gate-up", 22016, 4096, 3, True, False),
+                                          ("down", 4096, 11008, 0, False, False), ("lm_head", 49958, 4096, 0, True, True)):
+            a = rnd(1, K)
+            ws = [packw(N, K) for _ in range(6)]
+            gamma = torch.ones(K, device=DEV) if norm else None
+            res = None if (epi == 3 or f32) else rnd(1, N)
+            out = torch.empty(1, N // 2 if epi == 3 else N, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+            def run():
+                for w in ws:
+                    _lib.gemm(a, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, norm_gamma=gamma, norm_eps=1e-6)
+            t = timeit(run, reps=20) / len(ws)
+            if tag != "lm_head":
+                tot += t
+            print(f"gemv1 {tag:8s} N={N:6d} K={K:6d}  {t*1e6:7.2f} us  {N*K*2/t/1e9:7.0f} GB/s")
+            del ws
+        print(f"gemv1 layer GEMVs: {tot*1e6:.1f} us ({404.8e6/tot/1e9:.0f} GB/s over 404.8 MB)")
     if "dstream" in which:
         # batch-decode GEMMs: split-K panel kernel (8, + its reduce launches) vs the streaming kernel (9), bf16 and fp8 weights,
         # rotating over 4 weight buffers so the figures are HBM figures

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "gemv or gemm_shapes" 2>&1 | tail -3
+for g in 3 4; do VCLA_GEMV_OCC=$g python tools/bench_kernels.py gemv1 2>&1 | grep "gemv1 " | awk -v g=$g '{print "occ" g, $0}' | cut -c1-90 | grep -v "GB/s$" ; done
+for cfg in "VCLA_GEMV_OCC=3" "VCLA_GEMV_OCC=4"; do
+  echo "== $cfg"
+  env $cfg timeout 600 python bench.py --steps 2 --warmup 1 --steps-b64 0 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['unit'], d['ms_per_step'])"
+done
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "7b or small or tiny" 2>&1 | tail -3

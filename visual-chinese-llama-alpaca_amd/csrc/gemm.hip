@@ -1240,7 +1240,12 @@ static int launch_gemv1(const vcla_gemm_args* a, hipStream_t s) {
 static bool gemv1_applicable(const vcla_gemm_args* a, int dtype) {
     return dtype == VCLA_BF16 && a->M == 1 && a->K <= 15360 && (a->epilogue == VCLA_EPI_NONE || a->epilogue == VCLA_EPI_SWIGLU);
 }
+int vcla_gemv1x_launch(const vcla_gemm_args* a, hipStream_t s);   // gemv_decode.hip
 static int launch_gemv1_auto(const vcla_gemm_args* a, hipStream_t s) {
+    if (!(a->W_q8 && a->w_scale)) {   // compile-time-K form for the LLaMA widths; -1 = no instance for this K
+        const int rc = vcla_gemv1x_launch(a, s);
+        if (rc != -1) return rc;
+    }
     if (a->W_q8 && a->w_scale) {   // fp8 weight copy present: half the HBM bytes
         if (a->epilogue == VCLA_EPI_SWIGLU)
             return a->out_f32 ? launch_gemv1_fp8<2, true, float>(a, s) : launch_gemv1_fp8<2, true, bf16_t>(a, s);
