@@ -489,6 +489,26 @@ def test_gemv1x_llama_widths(lib, N, K, epi, f32out):
         _cmp(f"gemv1x[{N}x{K},epi{epi},norm{int(use_norm)}]", got, ref, atol=2e-4 if f32out else 4e-3, rtol=1e-5 if f32out else 8e-3)
 
 
+@pytest.mark.parametrize("N,K,epi,f32out", [(4096, 4096, 0, False), (22016, 4096, 3, False), (4096, 11008, 0, False), (49958, 4096, 0, True),
+                                            (1001, 11008, 0, False), (5120, 13824, 0, False)])
+def test_gemv1x_fp8_llama_widths(lib, N, K, epi, f32out):
+    """the fp8-weight instances of the same kernel: exactly the function of the dequantised weights, fp32 accumulate"""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows
+    g = torch.Generator().manual_seed(N + K + epi + 1)
+    x = bf16r(torch.randn(1, K, generator=g))
+    gamma = bf16r(1 + 0.1 * torch.randn(K, generator=g))
+    wp = _pack(bf16r(torch.randn(N, K, generator=g) * 0.05))
+    q, sc = quantize_fp8_rows(wp)
+    wdq = dequantize_fp8_rows(q, sc)[:N].cpu()
+    n_out = N // 2 if epi == 3 else N
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    res = bf16r(torch.randn(1, n_out, generator=g))
+    ref = _gemm_ref(O.llama_rmsnorm(x, gamma, 1e-6), wdq, bias, epi, res)
+    got = lib.gemm(x.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi, out_f32=f32out,
+                   w_q8=q, w_scale=sc, norm_gamma=gamma.to(DEV), norm_eps=1e-6)
+    _cmp(f"gemv1x_fp8[{N}x{K},epi{epi}]", got, ref, atol=3e-4 if f32out else 4e-3, rtol=1e-5 if f32out else 8e-3)
+
+
 # ------------------------------------------------------------------ fp8 (e4m3fn) decode weights
 @pytest.mark.parametrize("M,N,K,epi", [(1, 4096, 512, 0), (1, 2048, 1408, 3), (1, 1000, 4096, 0), (2, 512, 4096, 0), (16, 4096, 1408, 3),
                                        (64, 320, 640, 0), (128, 288, 2048, 3)])

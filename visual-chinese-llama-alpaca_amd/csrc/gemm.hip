@@ -1242,7 +1242,7 @@ static bool gemv1_applicable(const vcla_gemm_args* a, int dtype) {
 }
 int vcla_gemv1x_launch(const vcla_gemm_args* a, hipStream_t s);   // gemv_decode.hip
 static int launch_gemv1_auto(const vcla_gemm_args* a, hipStream_t s) {
-    if (!(a->W_q8 && a->w_scale)) {   // compile-time-K form for the LLaMA widths; -1 = no instance for this K
+    {   // compile-time-K persistent form for the LLaMA widths (bf16 and fp8 weights); -1 = no instance for this K
         const int rc = vcla_gemv1x_launch(a, s);
         if (rc != -1) return rc;
     }

@@ -27,12 +27,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int gv_u32x4;
 #define GV_WPB 8
 #define GV_OOB 0x80000000u
 
-template <int R, int K, bool SWIGLU, typename OutT>
+// FP8: W_q8 (OCP e4m3fn, one fp32 scale per row) instead of bf16 W -- a 16-byte load is 16 weights, a k-step 1024 elements
+template <int R, int K, bool SWIGLU, bool FP8, typename OutT>
 __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, int n_pad, int units) {
     constexpr int U = 4 / R;                 // a stage = 4 loads of 1 KiB per wave (U k-steps of R rows)
-    constexpr int NSTEP = (K + 511) / 512, NSTG = (NSTEP + U - 1) / U, DEPTH = NSTG < 3 ? NSTG : 3;
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [NSTEP * 512] x * gamma (zero past K), then [GV_WPB] partial sums of squares
-    float* red = xs + NSTEP * 512;
+    constexpr int EB = FP8 ? 1 : 2, LE = 16 / EB, SE = 64 * LE;   // bytes per weight, weights per lane-load, elements per k-step
+    constexpr int NSTEP = (K + SE - 1) / SE, NSTG = (NSTEP + U - 1) / U, DEPTH = NSTG < 3 ? NSTG : 3;
+    constexpr int KP = NSTEP * SE;           // K padded to whole k-steps
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [KP] x * gamma (zero past K), then [GV_WPB] partial sums of squares
+    float* red = xs + KP;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // unit = the R rows one wave reduces together (SwiGLU: the gate / up pair of one output); this workgroup owns units [lo, hi)
     const int lo = (int)((int64_t)blockIdx.x * units / gridDim.x), hi = (int)((int64_t)(blockIdx.x + 1) * units / gridDim.x);
@@ -42,10 +45,10 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
         if (SWIGLU) return (u >> 4) * 32 + (u & 15) + r * 16;                // 16-row gate block, 16-row up block, ...
         return u * R + r;                                                    // rows past N stay inside the 128-row padding of W
     };
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((int64_t)n_pad * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(FP8 ? a.W_q8 : a.W), 0, (int)((int64_t)n_pad * K * EB), 0x00020000);
     const unsigned voff = lane * 16;
     // lanes past K in the ragged last step: an offset beyond the buffer
-    const unsigned voff_last = ((NSTEP - 1) * 512 + lane * 8 < K) ? voff : GV_OOB;
+    const unsigned voff_last = ((NSTEP - 1) * SE + lane * LE < K) ? voff : GV_OOB;
 
     // one stage of unit-row offsets `ro` (GV_OOB in ro[0] = no such unit: every load of the stage is masked)
     // (the mask is laundered through an empty asm: a select the compiler can see through becomes a BRANCH around the loads, and
@@ -67,13 +70,13 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
     };
     auto row_offsets = [&](int i, unsigned (&ro)[R]) {                       // unit i of this wave (GV_OOB when past the end)
 #pragma unroll
-        for (int r = 0; r < R; ++r) ro[r] = i < nu ? (unsigned)unit_row(first + i * GV_WPB, r) * (unsigned)(K * 2) : GV_OOB;
+        for (int r = 0; r < R; ++r) ro[r] = i < nu ? (unsigned)unit_row(first + i * GV_WPB, r) * (unsigned)(K * EB) : GV_OOB;
     };
 
     // ---- x (and gamma) are requested first, the first DEPTH weight stages right behind them
     const bf16_t* X = (const bf16_t*)a.A;
     const bool fused_norm = a.norm_gamma != nullptr;
-    constexpr int NXI = (NSTEP * 512 + 4095) / 4096;     // staging passes of the 512 threads (8 elements each)
+    constexpr int NXI = (KP + 4095) / 4096;     // staging passes of the 512 threads (8 elements each)
     gv_u32x4 xraw[NXI];
     float4 g0[NXI], g1[NXI];
 #pragma unroll
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             const int k = i * 4096 + (int)threadIdx.x * 8;
-            if (k < NSTEP * 512) {
+            if (k < KP) {
                 float xv[8];
                 bf8_to_f32(__builtin_bit_cast(uint4, xraw[i]), xv);
                 if (fused_norm && k < K) {      // (the clamped loads past K must not reach the sum of squares)
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
     const int n_out = SWIGLU ? a.N / 2 : a.N;
     const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.residual), 0, a.residual ? n_out * 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? n_pad * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rScale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w_scale), 0, FP8 ? n_pad * 4 : 0, 0x00020000);
     for (int i = 0; i < nu; ++i) {
         const int unit = first + i * GV_WPB;
         // lane r < R finishes output r of the unit (SwiGLU: lane 0 the output, lanes 0 / 1 fetch the gate / up bias)
@@ -144,6 +148,8 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
         asm volatile("" : "+v"(evo), "+v"(bvo));
         const float res_v = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rRes, evo, 0, 0));
         const float bias_v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, bvo, 0, 0));
+        float wsc_v = 1.f;                               // fp8: dequantisation scale of this lane's row
+        if constexpr (FP8) wsc_v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rScale, bvo, 0, 0));
         __builtin_amdgcn_sched_barrier(0);
         unsigned ro_next[R];
         row_offsets(i + 1, ro_next);
@@ -157,15 +163,29 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
             for (int u = 0; u < U; ++u) {
                 const int st = sg * U + u;
                 if (st < NSTEP) {
-                    const int k = st * 512 + lane * 8;
-                    const float4 x0 = *reinterpret_cast<const float4*>(xs + k), x1 = *reinterpret_cast<const float4*>(xs + k + 4);
-                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    const int k = st * SE + lane * LE;
+                    float xv[LE];
+#pragma unroll
+                    for (int q = 0; q < LE / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4*>(xs + k + q * 4);
+                        xv[q * 4] = t.x; xv[q * 4 + 1] = t.y; xv[q * 4 + 2] = t.z; xv[q * 4 + 3] = t.w;
+                    }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        float wf[8];
-                        bf8_to_f32(__builtin_bit_cast(uint4, w[sg][u][r]), wf);
+                        if constexpr (FP8) {
+                            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[r] += wf[e] * xv[e];
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned d = w[sg][u][r][q];
+                                const f32x2_t lo2 = __builtin_amdgcn_cvt_pk_f32_fp8(d, false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8(d, true);
+                                acc[r] += lo2.x * xv[q * 4] + lo2.y * xv[q * 4 + 1] + hi2.x * xv[q * 4 + 2] + hi2.y * xv[q * 4 + 3];
+                            }
+                        } else {
+                            float wf[8];
+                            bf8_to_f32(__builtin_bit_cast(uint4, w[sg][u][r]), wf);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[r] += wf[e] * xv[e];
+                        }
                     }
                 }
             }
@@ -181,14 +201,14 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]) * rstd;
         if (SWIGLU) {
-            const float gt = acc[0] + bias_v, up = acc[1] + __shfl(bias_v, 1, 64);
+            const float gt = acc[0] * wsc_v + bias_v, up = acc[1] * __shfl(wsc_v, 1, 64) + __shfl(bias_v, 1, 64);
             const float v = act_silu(gt) * up + res_v;
             if (lane == 0) Act<OutT>::st(Cg + unit, v);
         } else {
             float v = acc[0];
 #pragma unroll
             for (int r = 1; r < R; ++r) v = lane == r ? acc[r] : v;
-            v += bias_v;
+            v = v * wsc_v + bias_v;
             v += res_v;
             const int n = unit * R + lane;
             if (lane < R && n < a.N) Act<OutT>::st(Cg + n, v);
@@ -204,9 +224,9 @@ __global__ __launch_bounds__(GV_WPB * 64) void gemv1p_kernel(vcla_gemm_args a, i
     }
 }
 
-template <int R, int K, bool SWIGLU, typename OutT>
+template <int R, int K, bool SWIGLU, bool FP8, typename OutT>
 static int launch_gemv1p(const vcla_gemm_args* a, hipStream_t s) {
-    constexpr int P = SWIGLU ? 1 : R, NSTEP = (K + 511) / 512;
+    constexpr int P = SWIGLU ? 1 : R, SE = FP8 ? 1024 : 512, KP = (K + SE - 1) / SE * SE;
     const int n_out = SWIGLU ? a->N / 2 : a->N;
     const int units = (n_out + P - 1) / P;
     const int n_pad = (a->N + 127) / 128 * 128;
@@ -217,31 +237,36 @@ static int launch_gemv1p(const vcla_gemm_args* a, hipStream_t s) {
         int occ = 0, dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemv1p_kernel<R, K, SWIGLU, OutT>, GV_WPB * 64, (size_t)(NSTEP * 512 + GV_WPB) * 4) != hipSuccess || occ < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemv1p_kernel<R, K, SWIGLU, FP8, OutT>, GV_WPB * 64, (size_t)(KP + GV_WPB) * 4) != hipSuccess || occ < 1)
             occ = 1;
         return prop.multiProcessorCount * (occ < occ_env ? occ : occ_env);
     }();
     int grid = (units + GV_WPB - 1) / GV_WPB;
     if (grid > per_cu) grid = per_cu;
-    gemv1p_kernel<R, K, SWIGLU, OutT><<<grid, GV_WPB * 64, (size_t)(NSTEP * 512 + GV_WPB) * 4, s>>>(*a, n_pad, units);
+    gemv1p_kernel<R, K, SWIGLU, FP8, OutT><<<grid, GV_WPB * 64, (size_t)(KP + GV_WPB) * 4, s>>>(*a, n_pad, units);
     VCLA_CHECK_LAUNCH("gemv1p_kernel");
     return VCLA_OK;
 }
 
 template <int K>
 static int launch_gemv1p_k(const vcla_gemm_args* a, hipStream_t s) {
+    if (a->W_q8 && a->w_scale) {   // fp8 rows are half as long: always 2 rows per wave, so that a stage is still 4 KiB
+        if (a->epilogue == VCLA_EPI_SWIGLU)
+            return a->out_f32 ? launch_gemv1p<2, K, true, true, float>(a, s) : launch_gemv1p<2, K, true, true, bf16_t>(a, s);
+        return a->out_f32 ? launch_gemv1p<2, K, false, true, float>(a, s) : launch_gemv1p<2, K, false, true, bf16_t>(a, s);
+    }
     if (a->epilogue == VCLA_EPI_SWIGLU)
-        return a->out_f32 ? launch_gemv1p<2, K, true, float>(a, s) : launch_gemv1p<2, K, true, bf16_t>(a, s);
+        return a->out_f32 ? launch_gemv1p<2, K, true, false, float>(a, s) : launch_gemv1p<2, K, true, false, bf16_t>(a, s);
     if (a->N >= 16384)  // very tall (lm_head): 2 rows per wave
-        return a->out_f32 ? launch_gemv1p<2, K, false, float>(a, s) : launch_gemv1p<2, K, false, bf16_t>(a, s);
-    return a->out_f32 ? launch_gemv1p<1, K, false, float>(a, s) : launch_gemv1p<1, K, false, bf16_t>(a, s);
+        return a->out_f32 ? launch_gemv1p<2, K, false, false, float>(a, s) : launch_gemv1p<2, K, false, false, bf16_t>(a, s);
+    return a->out_f32 ? launch_gemv1p<1, K, false, false, float>(a, s) : launch_gemv1p<1, K, false, false, bf16_t>(a, s);
 }
 
 // returns VCLA_OK (or a launch error) when it handled the call, -1 when this K has no compiled instance or the matrix is too
 // large for one buffer descriptor (the caller falls back to gemv1_kernel)
 int vcla_gemv1x_launch(const vcla_gemm_args* a, hipStream_t s) {
     static const int on = getenv("VCLA_GEMV1X") ? atoi(getenv("VCLA_GEMV1X")) : 1;
-    if (!on || a->M != 1 || !a->W) return -1;
+    if (!on || a->M != 1 || !(a->W || (a->W_q8 && a->w_scale))) return -1;
     if ((int64_t)((a->N + 127) / 128 * 128) * a->K * 2 >= (int64_t)1 << 31) return -1;
     switch (a->K) {
         case 4096: return launch_gemv1p_k<4096>(a, s);
