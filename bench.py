@@ -90,7 +90,7 @@ def _event_time(fn, reps: int):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def _pmc_traffic(stem: str = "r01_pmc_gemv1"):
+def _pmc_traffic(stem: str = "r02_pmc_gemv1p"):
     """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
     runs, FETCH_SIZE doubled per the gfx950 correction; tools/gpu_check.sh pmc).  Not collectable inside this run."""
     import re
@@ -105,8 +105,8 @@ def _pmc_traffic(stem: str = "r01_pmc_gemv1"):
 
 
 def gemv_roofline(model, n_rep: int = 20):
-    """Dominant kernel of the B = 1 workload: the gate/up SwiGLU GEMV with fused RMSNorm (gemv1_kernel<R=2,U=4,WPB=8,SWIGLU>; ~34 %
-    of the decode time, 43 % of the weight bytes).  One launch streams W_gu [2*11008, 4096] bf16 exactly once: algorithmic
+    """Dominant kernel of the B = 1 workload: the gate/up SwiGLU GEMV with fused RMSNorm (gemv1p_kernel<R=2,K=4096,SWIGLU>,
+    gemv_decode.hip; ~36 % of the decode time, 43 % of the weight bytes).  One launch streams W_gu [2*11008, 4096] bf16 exactly once: algorithmic
     bytes = 180.4 MB.  The 32 layers' matrices are launched back to back (5.8 GB footprint, so nothing is served from the 256 MB
     Infinity Cache) between two HIP events; achieved = bytes / mean launch duration (inter-launch gaps included)."""
     import torch
@@ -124,7 +124,7 @@ def gemv_roofline(model, n_rep: int = 20):
     sec = _event_time(run, n_rep) / L
     achieved = alg_bytes / sec / 1e9
     traffic, src = _pmc_traffic()
-    return {"bound": "hbm", "kernel": "gemv1_kernel<R=2,U=4,WPB=8,SWIGLU> (B=1 gate/up GEMV + fused RMSNorm, bf16)",
+    return {"bound": "hbm", "kernel": "gemv1p_kernel<R=2,K=4096,SWIGLU> (B=1 gate/up GEMV + fused RMSNorm, bf16, persistent)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(sec * 1e6, 2),
             "launches_timed": n_rep * L}

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT
+python tools/bench_kernels.py vit 2>&1 | grep "auto"
+rm -rf gpurun_out/pv
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/pv -o t -- python $R/tools/prof_vision.py 64 5 2>&1 | tail -1)
+f=$(find gpurun_out/pv -name "*kernel_trace.csv" | head -1)
+python tools/prof_by_grid.py $f 24 | tee gpurun_out/vision_by_grid.txt
+rm -rf gpurun_out/pv

@@ -26,7 +26,7 @@ if [ "$mode" = "pmc" ]; then
     rm -rf gpurun_out/pmc_$c
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_gemv.py 2>&1 | tail -2)
     f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python tools/pmc_summary.py "$f" $c | tee gpurun_out/pmc_$c.txt
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" $c gemv1p_kernel | tee gpurun_out/pmc_$c.txt
     find gpurun_out/pmc_$c -name "*.csv" -size +2M -delete
   done
   echo "== PMC MFMA utilisation of the 256x256 GEMM (LLaMA gate/up prefill shape)"

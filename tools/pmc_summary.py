@@ -6,7 +6,7 @@ import csv
 import sys
 
 path, counter = sys.argv[1], sys.argv[2]
-kernel_filter = sys.argv[3] if len(sys.argv) > 3 else "gemv1_kernel"
+kernel_filter = sys.argv[3] if len(sys.argv) > 3 else "gemv1p_kernel"
 vals = []
 with open(path) as f:
     for row in csv.DictReader(f):
