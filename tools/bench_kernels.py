@@ -15,6 +15,7 @@ DEV = "cuda:0"
 
 
 def timeit(fn, reps=20, warm=3):
+    reps = int(os.environ.get("VCLA_BENCH_REPS", reps))    # e.g. 400: a sustained run (tens of ms) instead of a ~3 ms burst
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -166,9 +167,10 @@ def main():
         skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
         for tag, N, K, epi in (("qkv", 3072, 1024, 0), ("out", 1024, 1024, 0), ("fc1", 4096, 1024, 1), ("fc2", 1024, 4096, 0)):
             a, w = rnd(Mv, K), packw(N, K)
+            bias = torch.randn(N, device=DEV)              # every CLIP linear carries a bias
             out = torch.empty(Mv, N, dtype=torch.bfloat16, device=DEV)
             for fk, nm in ((0, "auto"), (4, "256 "), (1, "128 ")):
-                t = timeit(lambda: _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws))
+                t = timeit(lambda: _lib.gemm(a, w, N, bias=bias, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws))
                 tf = 2.0 * Mv * N * K / t / 1e12
                 print(f"vit   {tag:4s} {nm} M={Mv} N={N:5d} K={K:5d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:.1f}% of peak)")
     if "skinny" in which:

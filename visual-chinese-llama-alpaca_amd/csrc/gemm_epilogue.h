@@ -28,16 +28,29 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
     // values of output tile jo (0 .. NOUT-1) of row tile i for this lane: bias / fp8 scales / activation / residual applied;
     // returns the first of the lane's 4 output columns
     constexpr int NOUT = (EPI == VCLA_EPI_SWIGLU) ? NJ / 2 : NJ;
+    // bias / fp8 weight scales of this lane's columns are the same for every row tile: fetched ONCE here.  (Inside the row loop
+    // the compiler cannot hoist them past the C stores -- nothing tells it that C and bias do not alias -- and a 256 x 256 tile
+    // paid 8 x 4 dependent loads per lane: the ViT GEMMs, which all carry a bias, ran 15-20 % slower in the model than the same
+    // shapes without bias in the microbenchmark.)
+    float bia[NJ][4], wsc[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nw + j * 16 + nq;            // packed column (SwiGLU: gate tiles 2jo, up tiles 2jo + 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bia[j][r] = (a.bias && (EPI == VCLA_EPI_SWIGLU || n + r < a.N)) ? a.bias[n + r] : 0.f;
+            wsc[j][r] = a.w_scale ? a.w_scale[n + r] : 1.f;      // n + r < N_pad always
+        }
+    }
     auto tile_vals = [&](int i, int jo, int m, float ascale, float (&v)[4]) -> int {
         int n;
         if constexpr (EPI == VCLA_EPI_SWIGLU) {
             n = nw / 2 + jo * 16 + nq;
-            const int np_ = nw + (2 * jo) * 16 + nq;  // packed column of the gate values (bias index)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float gt = acc[i][2 * jo][r], up = acc[i][2 * jo + 1][r];
-                if (a.w_scale) { gt *= a.w_scale[np_ + r] * ascale; up *= a.w_scale[np_ + 16 + r] * ascale; }
-                if (a.bias) { gt += a.bias[np_ + r]; up += a.bias[np_ + 16 + r]; }
+                if (a.w_scale) { gt *= wsc[2 * jo][r] * ascale; up *= wsc[2 * jo + 1][r] * ascale; }
+                if (a.bias) { gt += bia[2 * jo][r]; up += bia[2 * jo + 1][r]; }
                 v[r] = act_silu(gt) * up;
             }
         } else {
@@ -45,8 +58,8 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = acc[i][jo][r];
-                if (a.w_scale) x *= a.w_scale[n + r] * ascale;   // n + r < N_pad always
-                if (a.bias && n + r < a.N) x += a.bias[n + r];
+                if (a.w_scale) x *= wsc[jo][r] * ascale;
+                if (a.bias && n + r < a.N) x += bia[jo][r];
                 v[r] = epi_act<EPI>(x);
             }
         }
