@@ -412,6 +412,8 @@ def test_attn_decode_fused(lib, dtype, B, H, d, pos):
     (2, 3, 257, 257, 64, False), (1, 2, 64, 321, 64, False), (2, 4, 48, 48, 128, True), (1, 2, 130, 130, 128, True),
     (1, 2, 128, 128, 128, True), (2, 2, 100, 228, 128, True), (1, 1, 16, 16, 64, False), (1, 2, 577, 577, 64, False),
     (1, 1, 300, 1000, 128, True),
+    # bidirectional d = 64: 2 / 4 / 9 waves per workgroup by sequence length (attention_mfma.hip)
+    (3, 2, 129, 129, 64, False), (1, 1, 288, 288, 64, False), (2, 2, 100, 100, 64, False), (1, 2, 289, 200, 64, False), (2, 1, 33, 64, 64, False),
 ])
 def test_attention_mfma(lib, B, H, Tq, Tk, D, causal):
     g = torch.Generator().manual_seed(B * 3 + H + Tq + Tk + D)

@@ -1,8 +1,11 @@
 // attention_mfma.hip -- flash attention on v_mfma_f32_16x16x32_bf16 for the bf16 product path
 // (ViT bidirectional N=257 d=64, resampler cross attention 64 x 321 d=64, LLaMA causal prefill d=128).
 //
-// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows (two 16-row MFMA
-// tiles) and walks the keys in tiles of 64 staged through LDS once per workgroup.
+// Workgroup = NW waves = NW * 32 query rows of one (batch, head); each wave owns 32 query rows (two 16-row MFMA
+// tiles) and walks the keys in tiles of 64 staged through LDS once per workgroup.  NW = 4 for the causal prefill;
+// bidirectional attention over a short sequence takes the whole sequence in ONE workgroup when it fits (ViT: 257 rows =
+// 9 waves): K / V are staged once per (batch, head) instead of once per 128-row block -- with 4 waves the 257th row cost a
+// third workgroup that staged every tile for a single query (ViT attention at B = 64: 102 -> see profiles/).
 //
 // Both products are issued "swapped" so that the softmax row lives in ONE lane column:
 //   S^T = K . Q^T   (A port = K rows from LDS, B port = Q rows from registers)
@@ -19,7 +22,6 @@
 #include "vcla_common.h"
 
 #define FA_KV 64
-#define FA_QB 128
 
 template <int D> __device__ __forceinline__ int fa_k_off(int key, int ch) {
     if (D == 128) return key * 256 + ((ch ^ (key & 15)) << 4);
@@ -33,12 +35,13 @@ __device__ __forceinline__ int fa_key_pos(int key) {
     return ((t >> 1) << 5) + (g << 3) + ((t & 1) << 2) + r;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
+    constexpr int FA_QB = NW * 32, NT = NW * 64;
     constexpr int KST = D / 32;         // MFMA k-steps over the head dim (Q K^T)
     constexpr int DT = D / 16;          // 16-wide output d tiles (P V)
     constexpr int CH = D / 8;           // 16-byte chunks per K/V row
-    constexpr int NLD = (FA_KV * CH) / 256;  // staging loads per thread per operand
+    constexpr int NLD = (FA_KV * CH + NT - 1) / NT;  // staging loads per thread per operand
     __shared__ __attribute__((aligned(16))) unsigned char ks[FA_KV * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char vts[D * FA_KV * 2];
 
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int id = i * 256 + tid, key = id / CH, ch = id % CH;
+            const int id0 = i * NT + tid, id = id0 < FA_KV * CH ? id0 : FA_KV * CH - 1;   // (threads past the tile re-load its last chunk)
+            const int key = id / CH, ch = id % CH;
             int kg = tile * FA_KV + key;
             if (kg >= Tk) kg = Tk - 1;  // clamp; masked below
             rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)kg * a.k_rs + ch * 8);
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(vcla_attn_args a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int id = i * 256 + tid, key = id / CH, ch = id % CH;
+            const int id = i * NT + tid, key = id / CH, ch = id % CH;
+            if (id >= FA_KV * CH) continue;
             *reinterpret_cast<u32x4_t*>(ks + fa_k_off<D>(key, ch)) = rk[i];
             const int p = fa_key_pos(key);
             auto put2 = [&](uint32_t w, int e) {  // two adjacent d values of one key -> rows d, d+1 of V^T
@@ -236,10 +241,18 @@ bool vcla_attention_mfma_supported(const vcla_attn_args* a) {
 }
 
 int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
-    dim3 grid((a->Tq + FA_QB - 1) / FA_QB, a->H, a->B);
     hipStream_t s = (hipStream_t)stream;
-    if (a->D == 128) attn_mfma_kernel<128><<<grid, 256, 0, s>>>(*a);
-    else attn_mfma_kernel<64><<<grid, 256, 0, s>>>(*a);
+    static const int nw_env = getenv("VCLA_ATTN_MFMA_NW") ? atoi(getenv("VCLA_ATTN_MFMA_NW")) : 0;   // A/B runs: force 4
+    // waves per workgroup: bidirectional sequences longer than one 128-row block go 288 rows at a time (ViT-L/14 224 px: the
+    // whole sequence), 64-query cross attention (resampler) needs only 2 waves
+    int nw = 4;
+    if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : (a->Tq > 128 ? 9 : 4);
+    if (nw_env == 4) nw = 4;
+    dim3 grid((a->Tq + nw * 32 - 1) / (nw * 32), a->H, a->B);
+    if (a->D == 128) attn_mfma_kernel<128, 4><<<grid, 256, 0, s>>>(*a);
+    else if (nw == 9) attn_mfma_kernel<64, 9><<<grid, 576, 0, s>>>(*a);
+    else if (nw == 2) attn_mfma_kernel<64, 2><<<grid, 128, 0, s>>>(*a);
+    else attn_mfma_kernel<64, 4><<<grid, 256, 0, s>>>(*a);
     VCLA_CHECK_LAUNCH("attn_mfma_kernel");
     return VCLA_OK;
 }
