@@ -155,7 +155,8 @@ typedef struct vcla_gemm_args {
     void* C_frag;
     /* Deferred RMSNorm across two streaming GEMMs (LLaMA batch decode: o_proj -> post_attention_layernorm -> gate/up, down_proj ->
        next input_layernorm -> qkv).  PRODUCER side: c_frag_gamma [N] makes C_frag hold bf16(gamma[n] * C[m, n]) and c_row_ssq
-       [M][ceil(N/16)] receives, per row and 16-column tile, the sum of squares of the stored (rounded) C values.  CONSUMER side:
+       [M][ceil(N/16)] receives, per row and 16-column tile, the sum of squares of the stored (rounded) C values (with ds_splitk > 1 and
+       N % 256 == 0 the reduce launch writes one value per 256 columns instead: [M][N/256], packed at the front of the buffer).  CONSUMER side:
        a_row_ssq (the producer's c_row_ssq, a_row_ssq_parts partial sums per row) turns the accumulator of row m into
        acc * rsqrt(sum(a_row_ssq[m, :]) / K + a_norm_eps) before bias / activation: together
        W . (gamma * x) * rstd(x) = W . RMSNorm(x), with no norm launch in between.  Kernel 9 only. */

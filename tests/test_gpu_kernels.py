@@ -903,5 +903,19 @@ def test_gemm_dstream_splitk(lib, M, N, K, S, fp8):
     if cf is not None:
         assert torch.equal(lib.from_frag(cf, M).float().cpu(), bf16r(gamma * x))
     if ssq is not None:
-        _cmp("gemm_dstream_splitk.ssq", ssq.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
+        # the reduce launch writes one partial per 256 columns when N % 256 == 0 ([M][N/256], packed at the front of the buffer),
+        # else one per 16-column tile ([M][N/16])
+        parts = N // 256 if N % 256 == 0 else N // 16
+        rows = ssq.flatten()[:M * parts].view(M, parts)
+        _cmp("gemm_dstream_splitk.ssq", rows.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
+        if parts != N // 16:
+            assert float(ssq.flatten()[M * parts:].abs().max()) == 0.0
+            # ... and the consumer given that layout reproduces W2 . RMSNorm(x): same check as test_gemm_dstream_deferred_rmsnorm
+            g2 = torch.Generator().manual_seed(5)
+            w2 = bf16r(torch.randn(64, N, generator=g2) * 0.05)
+            w2p = _pack(w2)
+            got2 = lib.gemm(None, w2p, 64, force_kernel=9, a_frag=cf, m=M, w_frag=to_fragment_major(w2p), a_row_ssq=rows.contiguous(), a_norm_eps=1e-6)
+            rstd = torch.rsqrt((x * x).mean(1, keepdim=True) + 1e-6)
+            ref2 = _gemm_ref(bf16r(gamma * x) * rstd, w2, None, 0, None)      # what the kernels compute, in fp32
+            _cmp("gemm_dstream_splitk.consumer", got2, ref2, atol=2e-3, rtol=8e-3)
     assert torch.equal(outs[0][0], outs[1][0])

@@ -429,6 +429,7 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
+static thread_local int g_ssq_parts = 0;   // layout of the deferred-RMSNorm row statistics the last producer wrote (see gemm_ds)
 // streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
 static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
                    void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0, const float* a_ssq = nullptr,
@@ -437,6 +438,9 @@ static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const
     if (splitk > 1 && g_splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
         a.ds_splitk = splitk; a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
     }
+    // partial sums of squares per row this call leaves in c_ssq: the split-K reduce launch writes one per 256 columns (N % 256 ==
+    // 0), the in-kernel epilogue one per 16-column tile; the consumer (the next gemm_ds with a_ssq) must be told which
+    if (c_ssq) g_ssq_parts = (a.ds_splitk > 1 && (N & 255) == 0) ? N / 256 : N / 16;
     a.a_row_ssq = a_ssq; a.a_row_ssq_parts = a_parts; a.a_norm_eps = ctx->c.t_eps; a.c_frag_gamma = c_gamma; a.c_row_ssq = c_ssq;
     a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
@@ -566,7 +570,6 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         // GEMM scales its accumulators by rstd(x): W . (gamma * x) * rstd = W . RMSNorm(x).  5 launches per layer.
         static const int defer_env = getenv("VCLA_DS_DEFER") ? atoi(getenv("VCLA_DS_DEFER")) : 1;
         const bool defer = defer_env != 0 && D % 16 == 0;
-        const int parts = D / 16;
         // o_proj / down_proj (N = 4096 outputs, 16 columns per workgroup) are bound by re-reading the activations (a CU ingests only
         // ~45 GB/s from L2), not by the weights: K slices per tile group cut that traffic; a parallel reduce launch finishes the
         // tiles.  Measured at M = 64 (tools/bench_kernels.py dstream): down_proj 33.2 -> 25.7 us with 4 slices, o_proj 15.7 -> 15.0
@@ -576,12 +579,12 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         const float scale_ = 1.0f / sqrtf((float)d);
         if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
-                    defer && h_ready ? w.ssq : nullptr, parts));
+                    defer && h_ready ? w.ssq : nullptr, defer && h_ready ? g_ssq_parts : 0));
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
                                    scale_, dt, /*out_frag=*/1, s));
         if (defer) {
             RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq, sk_o));
-            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, parts));
+            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, g_ssq_parts));
             RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, next_gamma ? w.h : nullptr, M, D, c.t_inter, VCLA_EPI_NONE, 0, nullptr, 0,
                         next_gamma, next_gamma ? w.ssq : nullptr, sk_d));
         } else {
@@ -694,7 +697,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         const bool defer = defer_env != 0 && D % 16 == 0;     // the last down_proj left gamma_final * x and its row statistics in w.h / w.ssq
         if (!defer) RUN(vcla_rmsnorm_pack(w.x, D, ctx->norm_g, w.h, B, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, ctx->lm_head, ctx->vlm, nullptr, 0, lg, c.t_vocab, nullptr, B, c.t_vocab, D, VCLA_EPI_NONE, 1,
-                    defer ? w.ssq : nullptr, D / 16));
+                    defer ? w.ssq : nullptr, g_ssq_parts));
     } else if (ds_layers) {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, B, D, c.t_eps, dt, s));
         RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));

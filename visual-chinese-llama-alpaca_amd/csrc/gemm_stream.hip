@@ -294,7 +294,15 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(vcla_gemm_args a, int sp
         for (int r = 0; r < 4; ++r) { const float x = Act<OutT>::rnd(v[r]); q += live ? x * x : 0.f; }
         q += __shfl_xor(q, 1, 64);
         q += __shfl_xor(q, 2, 64);
-        if (live && (threadIdx.x & 3) == 0) a.c_row_ssq[(int64_t)m * (a.N >> 4) + (n >> 4)] = q;
+        if ((a.N & 255) == 0) {
+            // a wave = 256 consecutive columns of ONE row: reduce all the way, one partial per 256 columns (the consumer sums
+            // N / 256 values per row instead of N / 16: 4 KB instead of 64 KB per workgroup at M = 64, N = 4096)
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+            if (live && (threadIdx.x & 63) == 0) a.c_row_ssq[(int64_t)m * (a.N >> 8) + (n >> 8)] = q;
+        } else if (live && (threadIdx.x & 3) == 0) {
+            a.c_row_ssq[(int64_t)m * (a.N >> 4) + (n >> 4)] = q;
+        }
     }
     if (!live) return;
     if (a.C_frag) {
