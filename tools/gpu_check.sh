@@ -15,7 +15,7 @@ if [ "$mode" != "quick" ]; then
   echo "== bench fp8 B=1"; timeout 600 python bench.py --fp8 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_fp8.log
   echo "== bench sampled B=1"; timeout 600 python bench.py --sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_sample.log
   echo "== bench B=64"; timeout 600 python bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 | tee gpurun_out/bench_b64.log
-  echo "== kernel microbench"; timeout 900 python tools/bench_kernels.py vit 2>&1 | grep -v amdgpu.ids | tee gpurun_out/kernels.log
+  echo "== kernel microbench"; (timeout 900 python tools/bench_kernels.py gemv1 vit 2>&1; VCLA_BENCH_MS=64 timeout 600 python tools/bench_kernels.py dstream 2>&1) | grep -v amdgpu.ids | tee gpurun_out/kernels.log
   echo "== rocprof B=64"; rm -rf gpurun_out/prof64; (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof64 -o bench -- python $GRAFT_REPO_ROOT/bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -1); f=$(find gpurun_out/prof64 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-200; find gpurun_out/prof64 -name "*kernel_trace.csv" -delete
   echo "== rocprof"; rm -rf gpurun_out/prof; cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3
   cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*.csv" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"; find gpurun_out/prof -name "*kernel_trace.csv" -delete
