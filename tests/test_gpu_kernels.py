@@ -369,7 +369,9 @@ def test_gemv_fused_rmsnorm(lib, dtype, M, N, K, epi):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,d,pos", [(2, 4, 128, 37), (1, 3, 64, 200), (3, 2, 32, 5), (1, 2, 128, 0), (2, 2, 128, 700),
                                        # B*H >= 512 selects the row-cooperative score loop (batch decode)
-                                       (32, 16, 128, 190), (64, 8, 64, 3), (16, 32, 32, 65), (16, 32, 128, 0)])
+                                       (32, 16, 128, 190), (64, 8, 64, 3), (16, 32, 32, 65), (16, 32, 128, 0),
+                                       # B*H >= 1024 at d = 128: 2-wave workgroups (one round of workgroups at B = 64)
+                                       (64, 32, 128, 190), (40, 32, 128, 70), (33, 32, 128, 0), (64, 16, 128, 333)])
 def test_attn_decode_fused(lib, dtype, B, H, d, pos):
     from visualcla.weights import rope_tables
     ctx = max(64, (pos + 64) // 64 * 64)

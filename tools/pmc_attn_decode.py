@@ -11,7 +11,8 @@ import torch
 from visualcla import _lib
 from visualcla.weights import rope_tables
 
-B, H, d, ctx, pos = 64, 32, 128, 256, 192
+pos = int(os.environ.get("VCLA_PMC_POS", "192"))
+B, H, d, ctx = 64, 32, 128, (pos + 64) // 64 * 64
 dev = "cuda:0"
 L = _lib.load()
 cos, sin = (t.to(dev) for t in rope_tables(1024, d, 10000.0))

@@ -63,8 +63,11 @@ template <> struct Raw8<bf16_t> {
 // few dozen workgroups, B = 1).  COOP = true: D/8 adjacent lanes share a key row, so every load instruction of a wave
 // covers 64/(D/8) whole rows = 8 full cache lines instead of 64 partial ones -- with thousands of workgroups (batch decode)
 // the per-CU texture path, not latency, is what the one-key-per-thread form saturates.
-template <typename T, int D, bool COOP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+// NW = waves per workgroup.  4 everywhere except the batch form at short contexts (NW = 2, see launch_decode): the batch launch
+// is bounded by the dependent chain of a workgroup times the number of ROUNDS of workgroups, not by bandwidth; 2-wave
+// workgroups fit 8 per CU, i.e. B * H = 2048 (b, h) pairs in ONE round instead of two.
+template <typename T, int D, bool COOP, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                           T* __restrict__ out, int H, int ctx_max, int pos0,
                                                           const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
@@ -73,9 +76,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     float* qs = smem;              // [D]   roped query
     float* knew = smem + D;        // [D]   roped new key
     float* vnew = smem + 2 * D;    // [D]   new value
-    float* red = smem + 3 * D;     // [8]
-    float* part = smem + 3 * D + 8;  // [4][D] partial outputs
-    float* sc = part + 4 * D;      // [sc_cap] scores / probabilities
+    float* red = smem + 3 * D;     // [2 * NW]
+    float* part = smem + 3 * D + 2 * NW;  // [NW][D] partial outputs
+    float* sc = part + NW * D;     // [sc_cap] scores / probabilities
+    constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int pos = pos0 + (pos_dev ? *pos_dev : 0);   // position of the new token = number of cached keys
@@ -96,18 +100,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         knew[tid] = r0; knew[tid + HALF] = r1;
         Act<T>::st(kbase + (int64_t)pos * D + tid, r0);
         Act<T>::st(kbase + (int64_t)pos * D + tid + HALF, r1);
-    } else if (tid >= 128 && tid < 128 + D) {
-        const int i = tid - 128;
-        const float v = Act<T>::ld(row + 2 * HD + h * D + i);
-        vnew[i] = v;
-        Act<T>::st(vbase + (int64_t)pos * D + i, v);
+    } else if (NT >= 128 + D) {
+        if (tid >= 128 && tid < 128 + D) {
+            const int i = tid - 128;
+            const float v = Act<T>::ld(row + 2 * HD + h * D + i);
+            vnew[i] = v;
+            Act<T>::st(vbase + (int64_t)pos * D + i, v);
+        }
+    } else {
+        for (int i = tid - HALF; i < D; i += NT - HALF) {   // fewer threads than values: the threads past the RoPE lanes share them
+            const float v = Act<T>::ld(row + 2 * HD + h * D + i);
+            vnew[i] = v;
+            Act<T>::st(vbase + (int64_t)pos * D + i, v);
+        }
     }
     __syncthreads();
 
     // ---- V rows of the first P V pass are requested NOW: their latency overlaps the score / softmax phase below.  (Requesting
     // them -- or the K rows -- even earlier, before the RoPE phase, is slower: vmcnt retires in order, so the few small RoPE
     // loads would then wait behind ~24 row loads.  Measured 329 vs 332 tok/s at B = 1.)
-    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = 4 * KPW, UV = 8;
+    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = NW * KPW, UV = 8;
     const int vc_ = lane % LPK, vsub = wave * KPW + lane / LPK;   // chunk of the row, key slot within a block pass
     Raw8<T> vpre[UV];
 #pragma unroll
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
     float mx = -INFINITY;
     if constexpr (!COOP) {
-        for (int j = tid; j < Tk; j += 256) {
+        for (int j = tid; j < Tk; j += NT) {
             float sv;
             if (km && km[j] == 0) sv = -INFINITY;
             else if (j < pos) sv = scale * RowDot<T, D>::dot(qs, kbase + (int64_t)j * D);
@@ -178,22 +190,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float l = 0.f;
     if (mx > -INFINITY)
-        for (int j = tid; j < Tk; j += 256) {
+        for (int j = tid; j < Tk; j += NT) {
             const float e = __expf(sc[j] - mx);
             sc[j] = e;
             l += e;
         }
     l = wave_sum(l);
     __syncthreads();           // everyone has read red[] (max) before it is reused
-    if (lane == 0) red[4 + wave] = l;
+    if (lane == 0) red[NW + wave] = l;
     __syncthreads();
-    l = red[4] + red[5] + red[6] + red[7];
+    l = red[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) l += red[NW + w];
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     // probabilities rounded to the activation dtype before P V (HF: softmax(...).to(query.dtype))
-    for (int j = tid; j < Tk; j += 256) sc[j] = (mx > -INFINITY) ? Act<T>::rnd(sc[j] * inv) : 0.f;
+    for (int j = tid; j < Tk; j += NT) sc[j] = (mx > -INFINITY) ? Act<T>::rnd(sc[j] * inv) : 0.f;
     __syncthreads();
 
     // ---- P V.  LPK = D/8 adjacent lanes own the 8-dim chunks of ONE value row (16-byte loads, a full row per lane group),
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += sc[pos] * vnew[vc_ * 8 + e];
     }
-    // fold the KPW key slots of the wave (lanes LPK apart), then the 4 waves through LDS
+    // fold the KPW key slots of the wave (lanes LPK apart), then the NW waves through LDS
 #pragma unroll
     for (int off = LPK; off < 64; off <<= 1)
 #pragma unroll
@@ -250,7 +266,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         if (tid < D / 8) {
             float o8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = tid * 8 + e; o8[e] = part[c] + part[D + c] + part[2 * D + c] + part[3 * D + c]; }
+            for (int e = 0; e < 8; ++e) {
+                const int c = tid * 8 + e;
+                float t_ = part[c];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) t_ += part[w * D + c];
+                o8[e] = t_;
+            }
             const int k = h * D + tid * 8;
             T* dst = out + ((((int64_t)(k >> 5) * out_frag_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3);
             if constexpr (sizeof(T) == 2) {
@@ -261,7 +283,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
             }
         }
     } else if (tid < D) {
-        Act<T>::st(out + (int64_t)b * HD + h * D + tid, part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]);
+        float t_ = part[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t_ += part[w * D + tid];
+        Act<T>::st(out + (int64_t)b * HD + h * D + tid, t_);
     }
 }
 
@@ -270,13 +295,21 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
                          int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
                          float scale, int out_frag, hipStream_t s) {
     const int sc_cap = (ctx_max + 63) & ~63;
-    const size_t lds = (size_t)(3 * D + 8 + 4 * D + sc_cap) * sizeof(float);
+    // batch form: 2-wave workgroups (8 per CU: one round for B * H <= 2048) while the context is short enough that the extra
+    // passes over K and V (64 instead of 128 rows per pass) cost less than the second round of workgroups saves
+    // (measured at B = 64, H = 32, context 192: 46.0 -> 42.4 us per launch; VCLA_ATTN_NW=4 restores the 4-wave form)
+    static const int nw_env = getenv("VCLA_ATTN_NW") ? atoi(getenv("VCLA_ATTN_NW")) : 0;
+    const int NWs = (D == 128 && (int64_t)B * H >= 1024 && nw_env != 4) ? 2 : 4;
+    const size_t lds = (size_t)(3 * D + 2 * NWs + NWs * D + sc_cap) * sizeof(float);
     VCLA_REQUIRE(lds <= 64 * 1024, VCLA_ERR_BAD_SHAPE, "attn_decode: ctx_max=%d needs %zu B of LDS (max 64 KiB)", ctx_max, lds);
     dim3 grid(H, B);
     const int out_frag_mt = out_frag ? (B + 15) / 16 : 0;
     static const int coop_env = getenv("VCLA_ATTN_COOP") ? atoi(getenv("VCLA_ATTN_COOP")) : -1;   // -1 auto, 0 / 1 force (A/B runs)
     const bool coop = coop_env >= 0 ? coop_env != 0 : (int64_t)B * H >= 512;
-    if (coop)
+    if (coop && NWs == 2)
+        attn_decode_kernel<T, D, true, 2><<<grid, 128, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
+                                                                 pos_dev, key_mask, key_mask_ld, scale, sc_cap, out_frag_mt);
+    else if (coop)
         attn_decode_kernel<T, D, true><<<grid, 256, lds, s>>>((const T*)qkv, (T*)kc, (T*)vc, cos_tab, sin_tab, (T*)out, H, ctx_max, pos0,
                                                               pos_dev, key_mask, key_mask_ld, scale, sc_cap, out_frag_mt);
     else
