@@ -10,12 +10,14 @@ import torch
 from visualcla import _lib
 
 dev = "cuda:0"
-M, N, K = 8192, 22016, 4096
+vit = os.environ.get("VCLA_PMC_SHAPE", "") == "vit"       # ViT fc1: M = 16384 (the whole rounds), N = 4096, K = 1024, bias + quick-GELU
+M, N, K = (16384, 4096, 1024) if vit else (8192, 22016, 4096)
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16, device=dev)
 w.normal_(0, 0.02)
-out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
-for _ in range(5):
-    _lib.gemm(a, w, N, epilogue=_lib.EPI_SWIGLU, out=out, force_kernel=4)
+out = torch.empty(M, N if vit else N // 2, dtype=torch.bfloat16, device=dev)
+bias = torch.randn(N, device=dev) if vit else None
+for _ in range(20 if vit else 5):
+    _lib.gemm(a, w, N, bias=bias, epilogue=1 if vit else _lib.EPI_SWIGLU, out=out, force_kernel=4)
 torch.cuda.synchronize()
 print("done")
