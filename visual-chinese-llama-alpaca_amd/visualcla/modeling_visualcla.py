@@ -660,7 +660,7 @@ class VisualCLAModel:
         n_new = min(n_new, max_pos - T)
         if n_new <= 0:
             raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
-        ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64 + int(os.environ.get("VCLA_CTX_PAD", "0")))
+        ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
         cache = self._new_cache(B, ctx_max)
         key_mask = self._key_mask(attention_mask, B, T, ctx_max, extra)
         logits = self._prefill(embeds, cache, key_mask, all_logits=False)
