@@ -115,7 +115,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma256b", "skinny", "panel", "panel_ws", "panel_frag", "gemv", "gemv_generic", "gemv32", "f32"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_ws", "mfma256", "mfma256b", "skinny", "panel", "panel_ws", "panel_frag", "gemv", "gemv_generic", "gemv32", "f32"])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm(lib, kernel, epi, M, N, K):
@@ -133,8 +133,9 @@ def test_gemm(lib, kernel, epi, M, N, K):
     n_out = N // 2 if epi == 3 else N
     res = bf16r(torch.randn(M, n_out, generator=g))
     ref = _gemm_ref(a, w, bias, epi, res)
-    fk = {"mfma": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "panel": 8, "panel_ws": 8, "panel_frag": 8, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
-    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV) if kernel in ("panel_ws", "panel_frag") else None
+    fk = {"mfma": 1, "mfma_ws": 1, "mfma256": 4, "mfma256b": 5, "skinny": 7, "panel": 8, "panel_ws": 8, "panel_frag": 8, "gemv": 2, "gemv_generic": 6, "gemv32": 2, "f32": 3}[kernel]
+    # "mfma_ws": with a workspace the 128-tile kernel splits K when the problem has few tiles (e.g. 257 x 384 x 128 does not, 514 x 1024 x 1024 does)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV) if kernel in ("panel_ws", "panel_frag", "mfma_ws") else None
     wp = _pack(w)
     wf = None
     if kernel == "panel_frag":
@@ -149,6 +150,28 @@ def test_gemm(lib, kernel, epi, M, N, K):
         _cmp(f"gemm[{kernel},epi{epi},{M}x{N}x{K}]", got, ref, atol=1e-4, rtol=1e-5)
     else:
         _cmp(f"gemm[{kernel},epi{epi},{M}x{N}x{K}]", got, ref, atol=2e-3, rtol=8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(257, 1024, 4096, 0), (257, 4096, 1024, 1), (257, 3072, 1024, 0), (321, 2048, 1024, 2), (200, 4096, 11008, 0),
+                                       (257, 1024, 1024, 0), (300, 22016, 4096, 3)])
+def test_gemm_mfma128_splitk_single_image_shapes(lib, M, N, K, epi):
+    """the ViT / resampler GEMMs of ONE image (M = 257 / 321) and a 200-token LLaMA prefill: few 128 x 128 tiles, long K -> K slices
+    + reduce launch (launch_mfma); same function as the unsplit kernel, deterministic, fp32 output included"""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    ref = _gemm_ref(a, w, bias, epi, res)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    wp = _pack(w)
+    outs = [lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi, force_kernel=1,
+                     splitk_ws=ws) for _ in range(2)]
+    _cmp(f"gemm_mfma128_splitk[{M}x{N}x{K},epi{epi}]", outs[0], ref, atol=3e-3 if K > 8192 else 2e-3, rtol=8e-3)
+    assert torch.equal(outs[0], outs[1])
+    f32 = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), epilogue=epi, force_kernel=1, splitk_ws=ws, out_f32=True)
+    _cmp(f"gemm_mfma128_splitk_f32[{M}x{N}x{K},epi{epi}]", f32, _gemm_ref(a, w, bias, epi, None), atol=2e-4, rtol=2e-5)
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "gemv"])

@@ -246,7 +246,8 @@ int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     // waves per workgroup: bidirectional sequences longer than one 128-row block go 288 rows at a time (ViT-L/14 224 px: the
     // whole sequence), 64-query cross attention (resampler) needs only 2 waves
     int nw = 4;
-    if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : (a->Tq > 128 ? 9 : 4);
+    // (the 9-wave form needs B * H >= one workgroup per CU to pay: a single image is 16 heads = 16 workgroups, 48 with 4 waves)
+    if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : ((a->Tq > 128 && (int64_t)a->B * a->H >= 256) ? 9 : 4);
     if (nw_env == 4) nw = 4;
     dim3 grid((a->Tq + nw * 32 - 1) / (nw * 32), a->H, a->B);
     if (a->D == 128) attn_mfma_kernel<128, 4><<<grid, 256, 0, s>>>(*a);

@@ -41,8 +41,12 @@ __device__ __forceinline__ void tile_assign(int bid, int tiles_m, int tiles_n, i
 // byte offset of 16-byte chunk `ch` (0..7) of row `row` inside a [128][64] bf16 tile, XOR-swizzled
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int tiles_m, int tiles_n) {
+// SPLIT: blockIdx.y = K slice; the raw fp32 accumulators of the slice go to partial[ks][m][n_pad] and gemm_panel_reduce_kernel sums
+// the slices in order and applies the epilogue.  For problems of a few dozen tiles (the ViT / resampler GEMMs of a single image:
+// M = 257 -> 24 - 96 tiles for 256 CUs, 16 - 64 serial K steps each) -- see launch_mfma.
+template <int EPI, typename OutT, bool SPLIT = false>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int splitk = 1, int n_pad = 0,
+                                                        float* __restrict__ partial = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GM_BM * GM_BK * 2];  // [buf][A|W][16 KiB]
 
     int tm, tn;
@@ -53,8 +57,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- global -> register staging: 4 x 16 B per operand per thread
-    const bf16_t* Ag = (const bf16_t*)a.A;
-    const bf16_t* Wg = (const bf16_t*)a.W;
+    const int nk_all = a.K / GM_BK;
+    const int ks = SPLIT ? (int)blockIdx.y : 0;
+    const int k_beg = SPLIT ? (int)((int64_t)ks * nk_all / splitk) : 0, k_end = SPLIT ? (int)((int64_t)(ks + 1) * nk_all / splitk) : nk_all;
+    const bf16_t* Ag = (const bf16_t*)a.A + (int64_t)k_beg * GM_BK;
+    const bf16_t* Wg = (const bf16_t*)a.W + (int64_t)k_beg * GM_BK;
     const bf16_t* aptr[4];
     const bf16_t* wptr[4];
     int soff[4];
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
         soff[i] = lds_off(row, ch);
     }
     uint4 ra[4], rw[4];
-    const int nk = a.K / GM_BK;
+    const int nk = k_end - k_beg;                    // >= 1 (the launcher keeps splitk <= K / 64)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -132,7 +139,22 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
     }
     compute_tile((nk - 1) & 1);
 
-    gemm_epilogue<EPI, OutT, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    if constexpr (SPLIT) {
+        // acc[i][j][r] = C[m][n], m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r (operands swapped, see gemm_epilogue.h)
+        const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mw + i * 16 + (lane & 15);
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nw + j * 16 + (lane >> 4) * 4;      // < n_pad: W is padded to 128 rows
+                *reinterpret_cast<float4*>(partial + ((int64_t)ks * a.M + m) * n_pad + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    } else {
+        gemm_epilogue<EPI, OutT, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    }
 }
 
 // =================================================================== MFMA kernel, 256x256x64 tile, direct-to-LDS staging
@@ -1335,7 +1357,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(vcla_gemm_args a) {
 template <int EPI, typename OutT>
 static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + GM_BM - 1) / GM_BM, tiles_n = (a->N + GM_BN - 1) / GM_BN;
-    gemm_mfma_kernel<EPI, OutT><<<tiles_m * tiles_n, 256, 0, s>>>(*a, tiles_m, tiles_n);
+    const int tiles = tiles_m * tiles_n, nk = a->K / GM_BK;
+    // Few tiles, long K (one image through the ViT: 24 - 96 tiles on 256 CUs, 16 - 64 serial K steps): split K so that ~256
+    // workgroups run >= 4 K steps each; fp32 partial tiles + the panel kernel's reduce launch.  VCLA_MFMA128_SPLITK=0: off.
+    static const int sk_env = getenv("VCLA_MFMA128_SPLITK") ? atoi(getenv("VCLA_MFMA128_SPLITK")) : 1;
+    int S = 1;
+    if (sk_env && a->splitk_ws && tiles <= 128 && nk >= 8 && !a->post_norm_gamma) {
+        const int n_pad = (a->N + 127) / 128 * 128;
+        S = (256 + tiles - 1) / tiles;
+        if (S > nk / 4) S = nk / 4;
+        if (S > 8) S = 8;
+        while (S > 1 && (size_t)S * a->M * n_pad * 4 > a->splitk_ws_bytes) --S;
+    }
+    if (S > 1) {
+        const int n_pad = (a->N + 127) / 128 * 128;
+        gemm_mfma_kernel<EPI, OutT, true><<<dim3(tiles, S), 256, 0, s>>>(*a, tiles_m, tiles_n, S, n_pad, (float*)a->splitk_ws);
+        VCLA_CHECK_LAUNCH("gemm_mfma_kernel");
+        const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
+        const int64_t work = (int64_t)a->M * ((n_out + 3) / 4);
+        gemm_panel_reduce_kernel<EPI, OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, S, n_pad, (const float*)a->splitk_ws);
+        VCLA_CHECK_LAUNCH("gemm_panel_reduce_kernel");
+        return VCLA_OK;
+    }
+    gemm_mfma_kernel<EPI, OutT><<<tiles, 256, 0, s>>>(*a, tiles_m, tiles_n);
     VCLA_CHECK_LAUNCH("gemm_mfma_kernel");
     return VCLA_OK;
 }
