@@ -56,11 +56,29 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const T* __restrict__ s
 
 __global__ void advance_pos_kernel(int32_t* pos) { *pos += 1; }
 
-// ids_out[(*pos_dev - step_base) * B + b] = cur[b]
-__global__ void record_ids_kernel(const int64_t* __restrict__ cur, int64_t* __restrict__ ids_out,
-                                  const int32_t* __restrict__ pos_dev, int step_base, int B) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b < B) ids_out[(int64_t)(*pos_dev - step_base) * B + b] = cur[b];
+// End of a decode-loop step, ONE launch instead of three (record_ids + advance_pos + the next step's embed_splice): workgroup b
+//   ids_out[(*pos_dev - step_base) * B + b] = cur[b];   x[b, :] = embed[cur[b], :]  (the next step's decoder input);
+// the last workgroup to finish advances *pos_dev (every workgroup has read it by then) and re-arms the ticket.
+template <typename T>
+__global__ __launch_bounds__(256) void post_select_kernel(const int64_t* __restrict__ cur, int64_t* __restrict__ ids_out, int32_t* __restrict__ pos_dev,
+                                                          int step_base, int B, const bf16_t* __restrict__ table, T* __restrict__ x, int D, int V,
+                                                          int* __restrict__ ticket) {
+    const int b = blockIdx.x;
+    int64_t id = cur[b];
+    if (threadIdx.x == 0) ids_out[(int64_t)(*pos_dev - step_base) * B + b] = id;
+    if (id < 0 || id >= V) id = 0;          // as embed_splice_kernel: stay in bounds
+    const bf16_t* src = table + id * D;
+    T* o = x + (int64_t)b * D;
+    if constexpr (sizeof(T) == 2) {
+        for (int c = threadIdx.x * 8; c < D; c += 256 * 8) *reinterpret_cast<uint4*>(o + c) = *reinterpret_cast<const uint4*>(src + c);   // D % 8 == 0 (checked by the caller)
+    } else {
+        for (int c = threadIdx.x; c < D; c += 256) Act<T>::st(o + c, bf2f(src[c]));
+    }
+    __syncthreads();                        // thread 0's read of *pos_dev is done
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1) == B - 1) {
+        *pos_dev += 1;
+        *ticket = 0;
+    }
 }
 
 // ------------------------------------------------------------------ context
@@ -113,7 +131,8 @@ struct vcla_ctx {
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     int k_pad = 0;  // padded im2col width
     // cached decode graph
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec = nullptr;        // one decode step
+    hipGraphExec_t graph_exec_multi = nullptr;  // VCLA_GRAPH_STEPS decode steps (same key), built on the first loop long enough to use it
     struct {
         const void *ids, *kv, *mask, *ws, *out;
         int B, pos0, ctx_max, step_base;
@@ -162,6 +181,7 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
 extern "C" void vcla_ctx_destroy(vcla_ctx* ctx) {
     if (!ctx) return;
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph_exec_multi) (void)hipGraphExecDestroy(ctx->graph_exec_multi);
     delete ctx;
 }
 
@@ -359,6 +379,7 @@ struct LlamaWs {
     float* ssq;     // [64][t_hidden / 16] per-row partial sums of squares (deferred RMSNorm of the streaming decode GEMMs)
     void* q8;       // [M][max(t_hidden, t_inter)] fp8 copy of the activation operand (fp8 MFMA prefill, t_fp8_mfma)
     float* q8s;     // [M] its per-row scales
+    int* ticket;    // arrival counter of post_select_kernel (zeroed by the decode loop before its first step)
 };
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -376,6 +397,7 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.ids = (int64_t*)b.take((size_t)B * 8);
     t.splitk = b.take(SPLITK_WS_BYTES);
     t.ssq = (float*)b.take((size_t)64 * ((c.t_hidden + 15) / 16) * 4);
+    t.ticket = (int*)b.take(256);
     t.q8 = nullptr; t.q8s = nullptr;
     if (c.t_fp8_mfma && (size_t)B * T > 128) {
         t.q8 = b.take(M * (size_t)(c.t_hidden > c.t_inter ? c.t_hidden : c.t_inter));
@@ -677,12 +699,13 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
 
 static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
                             int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
-                            int64_t* ids_out, const LlamaWs& w, const vcla_sample_args* samp = nullptr, int n_hist0 = 0) {
+                            int64_t* ids_out, const LlamaWs& w, const vcla_sample_args* samp = nullptr, int n_hist0 = 0,
+                            bool skip_embed = false) {
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
     struct Scope { Scope() { g_decode_step = true; } ~Scope() { g_decode_step = false; } } decode_scope;
-    RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));
+    if (!skip_embed) RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));   // else: w.x was filled by post_select_kernel
     for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
                         l + 1 < c.t_layers ? ctx->llama[l + 1].ln1g : ctx->norm_g));
@@ -761,12 +784,20 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     // step_base: value of *pos_dev at the first step is unknown to the host -> the caller passes pos0 as the absolute
     // position of the first decoded token and keeps *pos_dev == 0 at entry (documented in INTEGRATION.md).
     const int step_base = 0;
+    const vcla_model_cfg& c = ctx->c;
+    // The first step's decoder input is embedded here; every later one by the post_select launch that ends the step before it
+    // (record the ids, embed them, advance the position: one launch instead of three per step).
+    RUN(vcla_embed_splice(w.ids, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, c.t_hidden, c.t_vocab, c.act_dtype, s));
+    VCLA_CHECK_HIP(hipMemsetAsync(w.ticket, 0, 4, s));
     auto one_step = [&](hipStream_t st) -> int {
-        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0));
-        record_ids_kernel<<<(B + 63) / 64, 64, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B);
-        VCLA_CHECK_LAUNCH("record_ids_kernel");
-        advance_pos_kernel<<<1, 1, 0, st>>>(pos_dev);
-        VCLA_CHECK_LAUNCH("advance_pos_kernel");
+        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0, /*skip_embed=*/true));
+        if (c.act_dtype == VCLA_BF16 && c.t_hidden % 8 == 0)
+            post_select_kernel<bf16_t><<<B, 256, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B, (const bf16_t*)ctx->embed, (bf16_t*)w.x, c.t_hidden, c.t_vocab, w.ticket);
+        else if (c.act_dtype == VCLA_BF16)
+            return vcla_fail(VCLA_ERR_BAD_SHAPE, "llama_decode_loop: hidden size %d is not a multiple of 8", c.t_hidden);
+        else
+            post_select_kernel<float><<<B, 256, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B, (const bf16_t*)ctx->embed, (float*)w.x, c.t_hidden, c.t_vocab, w.ticket);
+        VCLA_CHECK_LAUNCH("post_select_kernel");
         return VCLA_OK;
     };
     if (!use_graph || s == nullptr) {  // stream capture is illegal on the legacy default stream
@@ -779,22 +810,37 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
                       k.ws == ws && k.out == (const void*)ids_out && k.B == B && k.pos0 == pos0 && k.ctx_max == ctx_max &&
                       k.pos_dev == (const void*)pos_dev && k.step_base == step_base && k.has_samp == (sampling != nullptr) &&
                       (!sampling || (k.n_hist0 == n_hist0 && memcmp(&k.samp, sampling, sizeof(*sampling)) == 0));
-    if (!same) {
-        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+    // several steps per graph launch (VCLA_GRAPH_STEPS=4): measured EQUAL to one step per launch on MI355X (B = 1: 359.7 vs 359.3
+    // tok/s; the ~9 us between graph launches seen in round 1 are gone with the shorter step tail) -> off by default
+    static const int gsteps_env = getenv("VCLA_GRAPH_STEPS") ? atoi(getenv("VCLA_GRAPH_STEPS")) : 1;
+    const int G = gsteps_env > 1 ? gsteps_env : 1;
+    auto capture = [&](int count, hipGraphExec_t* out) -> int {
         hipGraph_t graph = nullptr;
         VCLA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int rc = one_step(s);
+        int rc = VCLA_OK;
+        for (int i = 0; i < count && !rc; ++i) rc = one_step(s);
         hipError_t ce = hipStreamEndCapture(s, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (ce != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-        hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+        hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) { ctx->graph_exec = nullptr; return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+        if (ie != hipSuccess) { *out = nullptr; return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+        return VCLA_OK;
+    };
+    if (!same) {
+        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        if (ctx->graph_exec_multi) { (void)hipGraphExecDestroy(ctx->graph_exec_multi); ctx->graph_exec_multi = nullptr; }
+        RUN(capture(1, &ctx->graph_exec));
         k.ids = w.ids; k.kv = kv_cache; k.mask = key_mask; k.ws = ws; k.out = ids_out; k.B = B; k.pos0 = pos0;
         k.ctx_max = ctx_max; k.pos_dev = pos_dev; k.step_base = step_base;
         k.has_samp = sampling != nullptr; k.n_hist0 = n_hist0;
         if (sampling) memcpy(&k.samp, sampling, sizeof(*sampling));
     }
-    for (int i = 0; i < n_steps; ++i) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, s));
+    int left = n_steps;
+    if (G > 1 && left >= G) {
+        if (!ctx->graph_exec_multi) RUN(capture(G, &ctx->graph_exec_multi));
+        for (; left >= G; left -= G) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec_multi, s));
+    }
+    for (; left > 0; --left) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, s));
     return VCLA_OK;
 }
