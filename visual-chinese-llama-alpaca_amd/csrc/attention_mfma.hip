@@ -141,31 +141,44 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
                 sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][s], sacc[1][t], 0, 0, 0);
             }
         }
-        // ---- masks + online softmax; lane holds keys kv0 + t*16 + g*4 + r of query rows qw + qt*16 + ql
-        // key-padding mask of the 64 keys of this tile as a wave-uniform bit mask (one load per lane + ballot)
-        unsigned long long tmask = ~0ull;
-        if (km) {  // wave-uniform
-            int key = kv0 + lane;
-            key = key < Tk ? key : Tk - 1;
-            tmask = __ballot(km[key] != 0);
+        // ---- masks + online softmax; lane holds keys kv0 + t*16 + g*4 + r of query rows qw + qt*16 + ql.
+        // At d = 64 this section, not the MFMAs, bounds the kernel (one v_exp + the VALU around it per score against 2 x 64 MFMA
+        // flops): the visibility test runs only on tiles that need one (wave-uniform: padding mask, the last tile, the causal
+        // diagonal), the row maximum is taken on the raw scores (scale > 0), and scale / max-subtraction are one FMA feeding a raw
+        // v_exp_f32.
+        const bool need_mask = km != nullptr || kv0 + FA_KV > Tk || (a.causal && kv0 + FA_KV - 1 > qw + coff);
+        if (need_mask) {
+            // key-padding mask of the 64 keys of this tile as a wave-uniform bit mask (one load per lane + ballot)
+            unsigned long long tmask = ~0ull;
+            if (km) {  // wave-uniform
+                int key = kv0 + lane;
+                key = key < Tk ? key : Tk - 1;
+                tmask = __ballot(km[key] != 0);
+            }
+            const unsigned long long lmask = tmask >> (g * 4);   // bit (t*16 + r) = key t*16 + g*4 + r
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int qrow = qw + qt * 16 + ql;
+                const int klim = a.causal ? (qrow + coff < Tk - 1 ? qrow + coff : Tk - 1) : Tk - 1;  // last visible key
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + t * 16 + g * 4 + r;
+                        const bool ok = (key <= klim) & (((lmask >> (t * 16 + r)) & 1ull) != 0);
+                        sacc[qt][t][r] = ok ? sacc[qt][t][r] : -INFINITY;
+                    }
+            }
         }
-        const unsigned long long lmask = tmask >> (g * 4);   // bit (t*16 + r) = key t*16 + g*4 + r
         bf16x8_t pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int qrow = qw + qt * 16 + ql;
-            const int klim = a.causal ? (qrow + coff < Tk - 1 ? qrow + coff : Tk - 1) : Tk - 1;  // last visible key
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + t * 16 + g * 4 + r;
-                    const bool ok = (key <= klim) & (((lmask >> (t * 16 + r)) & 1ull) != 0);
-                    const float sv = ok ? sacc[qt][t][r] * sl2 : -INFINITY;
-                    sacc[qt][t][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
+            mx *= sl2;                                   // log2 domain (-inf stays -inf)
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(sacc[qt][t][r] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][t][r], sl2, -m_use));   // raw v_exp_f32: exp2f() adds denormal-range scaling, ~4 VALU per score
                     pv[t * 4 + r] = p;
                     ps += p;
                 }
