@@ -168,6 +168,61 @@ def test_image_at_head_mode():
     assert out.shape == ref.shape and (out - ref).abs().max().item() <= 1e-3
 
 
+def test_masks_with_interior_zeros_are_refused():
+    """image_at_head=True + a left-padded text mask = [1]*Q ++ [0..0, 1..1] (modeling_visualcla.py:307-312): zeros between visible
+    tokens would give other relative RoPE distances than HF's cumsum positions -> ValueError, not a silently different result.
+    Left- and right-padded masks stay accepted."""
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, _, _ = O.make_inputs(cfg, 2, 24)
+    ids = torch.randint(3, 300, (2, 10))
+    mask = torch.ones_like(ids)
+    mask[1, :3] = 0
+    m = make_hip_model(cfg, W, torch.float32)
+    m.image_at_head = True
+    with pytest.raises(ValueError, match="between visible tokens"):
+        m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda())
+    with pytest.raises(ValueError, match="between visible tokens"):
+        m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=2, do_sample=False)
+    m.image_at_head = False
+    txt_mask = torch.ones_like(ids)
+    txt_mask[0, 4] = 0                                   # a hole in a text-only prompt
+    with pytest.raises(ValueError, match="between visible tokens"):
+        m.forward(input_ids=ids.cuda(), attention_mask=txt_mask.cuda())
+    right = torch.ones_like(ids)
+    right[1, 7:] = 0                                     # right padding: fine
+    m.forward(input_ids=ids.cuda(), attention_mask=right.cuda())
+    m.forward(input_ids=ids.cuda(), attention_mask=mask.cuda())      # left padding without the image prefix: fine
+
+
+@pytest.mark.parametrize("B", [2, 16, 64])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_single_token_forward_on_a_cache_matches_the_full_forward(B, dtype):
+    """forward(input_ids[B, 1], past_key_values=cache) -- the reference's forward contract (modeling_visualcla.py:264-330 passes
+    past_key_values through) -- against the full-sequence forward and the oracle.  2 <= B <= 64 single-token rows is exactly
+    the shape the streaming DECODE kernels serve: the prefill entry point must not take that branch (its tail expects a
+    row-major, normalised w.h)."""
+    cfg = O.cfg_small()
+    W = O.make_weights(cfg, seed=0)
+    T = 41
+    px, ids, mask = O.make_inputs(cfg, B, T + 1, n_prefix=4)
+    m = make_hip_model(cfg, W, dtype)
+    first = m.forward(input_ids=ids[:, :T].cuda(), pixel_values=px.cuda(), use_cache=True)
+    cache = first.past_key_values
+    assert cache is not None and cache.get_seq_length() == T
+    taps = {}
+    step = m.forward(input_ids=ids[:, T:].cuda(), past_key_values=cache, use_cache=True, taps=taps)
+    assert step.logits.shape == (B, 1, cfg.text.vocab_size) and cache.get_seq_length() == T + 1
+    full = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda()).logits[:, -1].float().cpu()
+    ref = O.visualcla_forward(ids[:4], px[:4], mask[:4], W, cfg)[:, -1]
+    got = step.logits[:, 0].float().cpu()
+    tol = 1e-3 if dtype == torch.float32 else 6e-2
+    e_full, e_ref = (got - full).abs().max().item(), (got[:4] - ref[: min(B, 4)]).abs().max().item()
+    _report(f"single-token forward on a cache [B={B}, {dtype}]: vs full forward {e_full:.3e}, vs oracle {e_ref:.3e}")
+    assert e_full <= tol and e_ref <= tol, (e_full, e_ref)
+    assert torch.isfinite(taps["final_norm"].float()).all()
+
+
 def test_state_dict_roundtrip_and_dtype_switch():
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)
@@ -360,7 +415,7 @@ def test_7b_batch64_decode_matches_full_forward(model_7b, fp8):
 B7_VIT_REL = 4e-2        # every ViT / resampler tap: max |err| / max |ref|
 B7_LOGIT_MAX = 0.9       # logits: max abs error
 B7_LOGIT_MEAN = 0.1      # logits: mean abs error
-B7_MARGIN = 1.0          # top-2 margin of the fp32 reference beyond which the bf16 argmax must agree
+B7_MARGIN = 0.5          # top-2 margin of the fp32 reference beyond which the bf16 argmax must agree (> the measured max error 0.45-0.49)
 
 
 def _oracle_threads():
@@ -573,3 +628,92 @@ def test_7b_fp8_mfma_prefill_error_is_bounded(model_7b):
     _report(f"7B fp8 MFMA prefill vs bf16 prefill [B={B},T={T}]: logits max err {err.max().item():.3e} mean {err.mean().item():.3e} "
             f"(logit std {std:.3f}, cosine {cos:.4f})")
     assert err.mean().item() <= 0.55 * std and cos >= 0.8
+
+
+def test_7b_batch64_rows_match_oracle(model_7b):
+    """BASELINE configs[2] (B = 64, T = 128) end to end against the ORACLE: the prefill's last-position logits and two
+    teacher-forced decode steps of rows {0, 37, 63} of a 64-row generate().  Rows are independent (no cross-sample reduction on
+    the path), so the oracle runs on those three rows only; the HIP side runs the B = 64 instances (256x256 prefill tiles,
+    streaming decode GEMMs with MT = 4, the 2-wave batch decode attention) that the benchmark's images_per_sec comes from."""
+    from transformers import LogitsProcessorList
+    m, ocfg = model_7b
+    _oracle_threads()
+    B, T, n_new = 64, 128, 3
+    rows = [0, 37, 63]
+    px, ids, mask = O.make_inputs(ocfg, B, T)
+    W = _w7(m)
+    seen = []
+
+    def grab(ids_, scores):
+        seen.append(scores[rows].detach().float().cpu().clone())
+        return scores
+    toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=n_new, do_sample=False,
+                      eos_token_id=None, logits_processor=LogitsProcessorList([grab])).cpu()
+    loop = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=n_new, do_sample=False,
+                      eos_token_id=None).cpu()          # the device-resident hipGraph loop the benchmark times: same kernels
+    assert torch.equal(loop, toks)
+    with torch.no_grad():
+        img = O.image_embeds(px[rows], W, ocfg)
+        x = O.embed_and_splice(ids[rows], img, W, ocfg)
+        cache = [None] * ocfg.text.num_hidden_layers
+        h = O.llama_forward(x, W, ocfg.text, mask[rows], cache, 0)
+        refs = [O.lm_head(h[:, -1:], W)[:, 0]]
+        past = T
+        for s_ in range(n_new - 1):
+            e = W["text_model.model.embed_tokens.weight"][toks[rows, s_]][:, None, :]
+            h = O.llama_forward(e, W, ocfg.text, torch.ones(len(rows), past + 1, dtype=torch.int64), cache, past)
+            refs.append(O.lm_head(h, W)[:, 0])
+            past += 1
+    for s_ in range(n_new):
+        e_ = (seen[s_] - refs[s_]).abs()
+        _report(f"7B B=64 rows {rows} {'prefill' if s_ == 0 else f'decode step {s_}'} logits vs fp32 oracle: max {e_.max().item():.3e} mean {e_.mean().item():.3e}")
+        assert e_.max().item() <= B7_LOGIT_MAX and e_.mean().item() <= B7_LOGIT_MEAN, (s_, e_.max().item(), e_.mean().item())
+        t2 = refs[s_].topk(2, dim=-1)
+        decided = (t2.values[:, 0] - t2.values[:, 1]) > B7_MARGIN
+        assert bool((seen[s_].argmax(-1) == t2.indices[:, 0])[decided].all())
+
+
+def test_7b_336px_vision_stack_matches_oracle(model_7b):
+    """BASELINE configs[4] patching at the 7B shape: 336 px -> N = 577 ViT tokens, 641 resampler keys (the ViT attention takes
+    the 4-wave / multi-block form here, the GEMMs other tile counts).  All 24 ViT taps, post-LN, the 6 resampler taps and the
+    projected image embeds of a B = 2 batch against the fp32 oracle with the bicubically grown position embedding
+    (models/visualcla/modeling_visualcla.py:13-43)."""
+    import copy
+    from visualcla.weights import extend_position_embedding
+    m, ocfg = model_7b
+    _oracle_threads()
+    W = _w7(m)
+    pos224 = m._packed["vit.pos"]
+    ocfg2 = copy.deepcopy(ocfg)
+    ocfg2.vision.image_size = 336
+    W2 = {k: v for k, v in W.items() if not k.startswith("text_model.")}
+    pe_key = next(k for k in W2 if k.endswith("vision_model.embeddings.position_embedding.weight"))
+    W2[pe_key] = W2[pe_key].clone()
+    extend_position_embedding(W2, ocfg.vision.patch_size, 336)
+    px, _, _ = O.make_inputs(ocfg2, 2, 128)
+    m.set_image_size(336)
+    try:
+        taps = {}
+        m.embed_images(px.cuda(), taps)
+        torch.cuda.synchronize()
+    finally:            # back to the 224-px model the other tests of this module share (same tensor, not a second interpolation)
+        m.config.vision_config["image_size"] = 224
+        m.vision_model.config.image_size = 224
+        m._packed["vit.pos"] = pos224
+        m._ws.clear()
+        m._build_ctx()
+    ref_t = {}
+    with torch.no_grad():
+        O.image_embeds(px, W2, ocfg2, ref_t)
+    worst, n = 0.0, 0
+    for k, ref in ref_t.items():
+        if k not in taps:
+            continue
+        got = taps[k].float().cpu().reshape(ref.shape)
+        err = (got - ref).abs()
+        rel = err.max().item() / max(ref.abs().max().item(), 1e-6)
+        worst, n = max(worst, rel), n + 1
+        _report(f"7B@336px bf16 vs fp32 oracle {k}: max_abs_err={err.max().item():.3e} mean={err.mean().item():.3e} rel_to_absmax={rel:.3e}")
+        assert rel <= B7_VIT_REL, (k, rel)
+    assert n >= 24 + 1 + 6 + 1 and ref_t["vit_post_ln"].shape[1] == 577
+    _report(f"7B@336px vision stack (N=577, KV=641): worst tap error {worst:.3e} of the tap's dynamic range (bound {B7_VIT_REL})")

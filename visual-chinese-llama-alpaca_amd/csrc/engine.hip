@@ -130,6 +130,16 @@ struct vcla_ctx {
     WVar vlm;
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     int k_pad = 0;  // padded im2col width
+    // per-call state of the macro entry points (one thread drives a context at a time): the workspace carve of the
+    // running call and what the last streaming GEMM left behind.  Kept here, not in thread-local globals, so that nothing
+    // leaks between contexts or into the public vcla_gemm entry point.
+    struct {
+        void* splitk_ws = nullptr;     // fp32 split-K scratch of the running entry point's workspace
+        bool decode_step = false;      // inside decode_step_impl: the fp8 weight copies (if loaded) may be used
+        void* q8_ws = nullptr;         // fp8 activation staging of the running prefill (t_fp8_mfma), else NULL
+        float* q8s_ws = nullptr;
+        int ssq_parts = 0;             // layout of the deferred-RMSNorm row statistics the last producer wrote (see gemm_ds)
+    } run;
     // cached decode graph
     hipGraphExec_t graph_exec = nullptr;        // one decode step
     hipGraphExec_t graph_exec_multi = nullptr;  // VCLA_GRAPH_STEPS decode steps (same key), built on the first loop long enough to use it
@@ -416,12 +426,7 @@ extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
 }
 
 // ------------------------------------------------------------------ small wrappers
-static thread_local void* g_splitk_ws = nullptr;  // set by the macro entry points from their workspace carve
-static thread_local bool g_decode_step = false;   // inside decode_step_impl: the fp8 weight copies (if loaded) may be used
-static thread_local void* g_q8_ws = nullptr;      // fp8 activation staging of the running prefill (t_fp8_mfma), else NULL
-static thread_local float* g_q8s_ws = nullptr;
-
-static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
+static int gemm(vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const void* W, const float* bias,
                 const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, int out_f32 = 0,
                 int grp_rows = 0, int grp_stride = 0, int row_off = 0, const float* norm_gamma = nullptr, float norm_eps = 0.f,
                 const WVar* wv = nullptr, const float* post_gamma = nullptr, float post_eps = 0.f, void* post_out = nullptr,
@@ -433,40 +438,39 @@ static int gemm(const vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, 
     a.c_group_rows = grp_rows; a.c_group_stride = grp_stride; a.c_row_offset = row_off;
     a.force_kernel = 0;
     a.norm_gamma = norm_gamma; a.norm_eps = norm_eps;
-    a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = g_splitk_ws ? SPLITK_WS_BYTES : 0;
-    if (wv && wv->q8 && wv->s8 && g_q8_ws && M > 128 && K % 128 == 0 && lda == K && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0) {
+    a.splitk_ws = ctx->run.splitk_ws; a.splitk_ws_bytes = ctx->run.splitk_ws ? SPLITK_WS_BYTES : 0;
+    if (wv && wv->q8 && wv->s8 && ctx->run.q8_ws && M > 128 && K % 128 == 0 && lda == K && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0) {
         // BASELINE configs[4]: prefill on the fp8 MFMA pipe -- quantise the activation rows (one pass over M x K), then fp8 x fp8
-        int rc = vcla_quant_fp8_rows(A, lda, g_q8_ws, g_q8s_ws, M, K, s);
+        int rc = vcla_quant_fp8_rows(A, lda, ctx->run.q8_ws, ctx->run.q8s_ws, M, K, s);
         if (rc) return rc;
-        a.A = nullptr; a.A_q8 = g_q8_ws; a.a_scale = g_q8s_ws; a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 10;
+        a.A = nullptr; a.A_q8 = ctx->run.q8_ws; a.a_scale = ctx->run.q8s_ws; a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 10;
         return vcla_gemm(&a, ctx->c.act_dtype, s);
     }
     if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)
-        // fp8 copies (when loaded) serve the DECODE steps only (g_decode_step; a short prefill keeps the bf16 values): half the HBM
+        // fp8 copies (when loaded) serve the DECODE steps only (ctx->run.decode_step; a short prefill keeps the bf16 values): half the HBM
         // bytes.  M = 1 GEMV: 1.3x end to end; panel kernel: 112 vs 132 us per layer at
         // M = 64, 88 vs 111 us at M = 32 (tools/bench_kernels.py panel, after the fetch-past-the-slice fix)
-        if (g_decode_step && wv->q8 && wv->q8f && wv->s8) { a.W_q8 = wv->q8; a.W_q8_frag = wv->q8f; a.w_scale = wv->s8; }
+        if (ctx->run.decode_step && wv->q8 && wv->q8f && wv->s8) { a.W_q8 = wv->q8; a.W_q8_frag = wv->q8f; a.w_scale = wv->s8; }
         else a.W_frag = wv->frag;
     }
     return vcla_gemm(&a, ctx->c.act_dtype, s);
 }
 
-static thread_local int g_ssq_parts = 0;   // layout of the deferred-RMSNorm row statistics the last producer wrote (see gemm_ds)
 // streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
-static int gemm_ds(const vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
+static int gemm_ds(vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
                    void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0, const float* a_ssq = nullptr,
                    int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr, int splitk = 0) {
     vcla_gemm_args a{};
-    if (splitk > 1 && g_splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
-        a.ds_splitk = splitk; a.splitk_ws = g_splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
+    if (splitk > 1 && ctx->run.splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
+        a.ds_splitk = splitk; a.splitk_ws = ctx->run.splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
     }
     // partial sums of squares per row this call leaves in c_ssq: the split-K reduce launch writes one per 256 columns (N % 256 ==
     // 0), the in-kernel epilogue one per 16-column tile; the consumer (the next gemm_ds with a_ssq) must be told which
-    if (c_ssq) g_ssq_parts = (a.ds_splitk > 1 && (N & 255) == 0) ? N / 256 : N / 16;
+    if (c_ssq) ctx->run.ssq_parts = (a.ds_splitk > 1 && (N & 255) == 0) ? N / 256 : N / 16;
     a.a_row_ssq = a_ssq; a.a_row_ssq_parts = a_parts; a.a_norm_eps = ctx->c.t_eps; a.c_frag_gamma = c_gamma; a.c_row_ssq = c_ssq;
     a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
-    if (g_decode_step && wv.q8f && wv.s8) { a.W_q8_frag = wv.q8f; a.w_scale = wv.s8; }
+    if (ctx->run.decode_step && wv.q8f && wv.s8) { a.W_q8_frag = wv.q8f; a.w_scale = wv.s8; }
     else a.W_frag = wv.frag;
     return vcla_gemm(&a, VCLA_BF16, s);
 }
@@ -498,7 +502,7 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
     const int g = c.v_image / c.v_patch, np = g * g, N = np + 1, D = c.v_hidden, H = c.v_heads, d = D / H;
     VisionWs w;
     carve_vision(ctx, B, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
-    g_splitk_ws = w.splitk;
+    ctx->run.splitk_ws = w.splitk;
     const int M = B * N;
 
     // patch embedding: im2col -> GEMM (no bias) -> class/position embedding + pre-LN
@@ -586,7 +590,10 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     // no split-K partials.
     static const int ds_env = getenv("VCLA_DSTREAM") ? atoi(getenv("VCLA_DSTREAM")) : 1;
     const bool has_frag = (L.vqkv.frag && L.vo.frag && L.vgu.frag && L.vd.frag) || (L.vqkv.q8f && L.vo.q8f && L.vgu.q8f && L.vd.q8f);
-    if (ds_env && T == 1 && dt == VCLA_BF16 && M >= 2 && M <= 64 && has_frag && D % 32 == 0 && c.t_inter % 32 == 0) {
+    // Decode steps only (ctx->run.decode_step): the branch leaves w.h fragment-major and un-normalised, which decode_step_impl's
+    // final norm + lm_head expect and vcla_llama_prefill's all_logits tail (row-major w.h) does not -- a single-token
+    // forward(input_ids[B, 1], past_key_values=cache) goes through the panel kernels below.
+    if (ds_env && ctx->run.decode_step && T == 1 && dt == VCLA_BF16 && M >= 2 && M <= 64 && has_frag && D % 32 == 0 && c.t_inter % 32 == 0) {
         // RMSNorm is deferred across the GEMMs (VCLA_DS_DEFER=0: a vcla_rmsnorm_pack launch per norm instead): o_proj / down_proj
         // store gamma * x fragment-major next to the residual stream plus per-row partial sums of squares, and the consuming
         // GEMM scales its accumulators by rstd(x): W . (gamma * x) * rstd = W . RMSNorm(x).  5 launches per layer.
@@ -601,12 +608,12 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         const float scale_ = 1.0f / sqrtf((float)d);
         if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
-                    defer && h_ready ? w.ssq : nullptr, defer && h_ready ? g_ssq_parts : 0));
+                    defer && h_ready ? w.ssq : nullptr, defer && h_ready ? ctx->run.ssq_parts : 0));
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
                                    scale_, dt, /*out_frag=*/1, s));
         if (defer) {
             RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq, sk_o));
-            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, g_ssq_parts));
+            RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, ctx->run.ssq_parts));
             RUN(gemm_ds(ctx, s, w.act, L.wd, L.vd, w.x, D, w.x, D, next_gamma ? w.h : nullptr, M, D, c.t_inter, VCLA_EPI_NONE, 0, nullptr, 0,
                         next_gamma, next_gamma ? w.ssq : nullptr, sk_d));
         } else {
@@ -674,8 +681,8 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     const int D = c.t_hidden, M = B * T;
     LlamaWs w;
     carve_llama(ctx, B, T, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
-    g_splitk_ws = w.splitk;
-    struct Q8Scope { Q8Scope(void* q, float* s_) { g_q8_ws = q; g_q8s_ws = s_; } ~Q8Scope() { g_q8_ws = nullptr; g_q8s_ws = nullptr; } } q8_scope(w.q8, w.q8s);
+    ctx->run.splitk_ws = w.splitk;
+    struct Q8Scope { vcla_ctx* c; Q8Scope(vcla_ctx* c_, void* q, float* s_) : c(c_) { c->run.q8_ws = q; c->run.q8s_ws = s_; } ~Q8Scope() { c->run.q8_ws = nullptr; c->run.q8s_ws = nullptr; } } q8_scope(ctx, w.q8, w.q8s);
     VCLA_CHECK_HIP(hipMemcpyAsync(w.x, inputs_embeds, (size_t)M * D * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < c.t_layers; ++l) {
         // every layer's down_proj also emits the next norm into w.h (the final norm only when all rows need it)
@@ -704,7 +711,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
-    struct Scope { Scope() { g_decode_step = true; } ~Scope() { g_decode_step = false; } } decode_scope;
+    struct Scope { vcla_ctx* c; explicit Scope(vcla_ctx* c_) : c(c_) { c->run.decode_step = true; } ~Scope() { c->run.decode_step = false; } } decode_scope(ctx);
     if (!skip_embed) RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));   // else: w.x was filled by post_select_kernel
     for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
@@ -720,7 +727,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         const bool defer = defer_env != 0 && D % 16 == 0;     // the last down_proj left gamma_final * x and its row statistics in w.h / w.ssq
         if (!defer) RUN(vcla_rmsnorm_pack(w.x, D, ctx->norm_g, w.h, B, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, ctx->lm_head, ctx->vlm, nullptr, 0, lg, c.t_vocab, nullptr, B, c.t_vocab, D, VCLA_EPI_NONE, 1,
-                    defer ? w.ssq : nullptr, g_ssq_parts));
+                    defer ? w.ssq : nullptr, ctx->run.ssq_parts));
     } else if (ds_layers) {
         RUN(vcla_rmsnorm(w.x, D, ctx->norm_g, w.h, D, B, D, c.t_eps, dt, s));
         RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
@@ -755,7 +762,7 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
     RUN(check_decode_args(ctx, ids_in, B, pos0, pos_dev, kv_cache, ctx_max, ws, ws_bytes));
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
-    g_splitk_ws = w.splitk;
+    ctx->run.splitk_ws = w.splitk;
     return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
                             logits, ids_out, w);
 }
@@ -778,7 +785,7 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     hipStream_t s = (hipStream_t)stream;
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
-    g_splitk_ws = w.splitk;
+    ctx->run.splitk_ws = w.splitk;
     // w.ids holds the current token of every sequence; each step consumes it and overwrites it with the argmax.
     VCLA_CHECK_HIP(hipMemcpyAsync(w.ids, ids_in, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
     // step_base: value of *pos_dev at the first step is unknown to the host -> the caller passes pos0 as the absolute

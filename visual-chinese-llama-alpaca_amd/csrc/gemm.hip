@@ -380,11 +380,8 @@ static int launch_mfma256_fp8(const vcla_gemm_args* a, hipStream_t s) {
     const int n_pad = (a->N + 127) / 128 * 128;
     const size_t lds = 4 * G2_TILE_BYTES;  // 128 KiB
     auto kern = gemm_mfma256_fp8_kernel<EPI, OutT>;
-    static bool attr_set = false;          // per instantiation
-    if (!attr_set) {
-        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
+    { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     static const int pg8 = getenv("VCLA_GEMM_PERSIST") ? atoi(getenv("VCLA_GEMM_PERSIST")) : 0;   // measured equal (see gemm_mfma256_kernel)
     const int nt8 = tiles_m * tiles_n;
     kern<<<(pg8 && nt8 > 256) ? 256 : nt8, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);   // one workgroup per CU, persistent over tiles
@@ -1390,11 +1387,8 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     const int n_pad = (a->N + 127) / 128 * 128;
     const size_t lds = 4 * G2_TILE_BYTES;  // 128 KiB
     auto kern = gemm_mfma256_kernel<EPI, OutT, SGB>;
-    static bool attr_set = false;          // per instantiation
-    if (!attr_set) {
-        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
+    { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     static const int pg = getenv("VCLA_GEMM_PERSIST") ? atoi(getenv("VCLA_GEMM_PERSIST")) : 0;   // measured equal: ViT fc1 180 vs 182 us, LLaMA gate/up 1288 vs 1265 us
     const int nt = tiles_m * tiles_n;
     kern<<<(pg && nt > 256) ? 256 : nt, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);   // one workgroup per CU, persistent over tiles
@@ -1547,6 +1541,8 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(!a->c_row_ssq || (a->epilogue == VCLA_EPI_NONE && !a->out_f32 && a->N % 16 == 0), VCLA_ERR_BAD_ARG,
                      "gemm: c_row_ssq needs epilogue NONE, a bf16 output and N %% 16 == 0");
         VCLA_REQUIRE(!a->a_row_ssq || a->a_row_ssq_parts > 0, VCLA_ERR_BAD_ARG, "gemm: a_row_ssq needs a_row_ssq_parts > 0");
+        VCLA_REQUIRE(!(a->a_row_ssq && a->ds_splitk > 1), VCLA_ERR_BAD_ARG,
+                     "gemm: a_row_ssq (deferred RMSNorm of the A operand) cannot be combined with ds_splitk > 1: the split-K reduce launch does not apply rstd");
         VCLA_REQUIRE(a->ds_splitk <= 1 || (a->epilogue == VCLA_EPI_NONE && a->ds_splitk <= 16 && a->N % 4 == 0 && (a->ldc % 4 == 0 || !a->C) && a->splitk_ws &&
                                            a->splitk_ws_bytes >= (size_t)a->ds_splitk * a->M * a->N * 4 && (!a->residual || a->ldr % 4 == 0) &&
                                            (!a->c_row_ssq || a->N % 16 == 0) && a->K / (a->W_q8_frag ? 64 : 32) >= a->ds_splitk),

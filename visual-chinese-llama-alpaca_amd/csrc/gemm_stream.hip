@@ -323,11 +323,8 @@ static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
     const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU) + rstd[64]
     auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        VCLA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
+    { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
     VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
     if constexpr (EPI == VCLA_EPI_NONE) {

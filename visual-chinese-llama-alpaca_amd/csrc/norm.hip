@@ -285,8 +285,8 @@ extern "C" int vcla_rmsnorm_pack(const void* x, int64_t ldx, const float* gamma,
 
 
 extern "C" int vcla_quant_fp8_rows(const void* x, int64_t ldx, void* q, float* scale, int rows, int cols, void* stream) {
-    VCLA_REQUIRE(rows >= 0 && cols > 0 && cols % 16 == 0 && cols <= 16384 && ldx % 8 == 0, VCLA_ERR_BAD_SHAPE,
-                 "quant_fp8_rows: rows=%d cols=%d (multiple of 16, max 16384), ldx=%lld", rows, cols, (long long)ldx);
+    VCLA_REQUIRE(rows >= 0 && cols > 0 && cols % 16 == 0 && cols <= 16128 && ldx % 8 == 0, VCLA_ERR_BAD_SHAPE,   // cols * 4 B of dynamic LDS + 16 B static <= 64 KiB
+                 "quant_fp8_rows: rows=%d cols=%d (multiple of 16, max 16128), ldx=%lld", rows, cols, (long long)ldx);
     VCLA_REQUIRE(x && q && scale && vcla_aligned(x, 16) && vcla_aligned(q, 16), VCLA_ERR_BAD_ARG, "quant_fp8_rows: null / misaligned pointer");
     if (rows == 0) return VCLA_OK;
     quant_fp8_rows_kernel<<<rows, 256, (size_t)cols * 4, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (unsigned char*)q, scale, cols);

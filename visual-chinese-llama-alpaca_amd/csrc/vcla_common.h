@@ -43,6 +43,20 @@ int vcla_fail(int code, const char* fmt, ...);
 int vcla_sample_launch(float* logits, int64_t ld, int B, int V, int n_hist, const int32_t* n_hist_dev, const vcla_sample_args* a,
                        int64_t* out, hipStream_t s);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): raise it once per device a kernel instantiation
+// is launched on (`done` = a static flag array of that instantiation), not once per process
+#define VCLA_MAX_DEVICES 32
+static inline int vcla_raise_dyn_lds(const void* kern, size_t bytes, bool (&done)[VCLA_MAX_DEVICES]) {
+    int dev = 0;
+    VCLA_CHECK_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < VCLA_MAX_DEVICES;
+    if (!tracked || !done[dev]) {
+        VCLA_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (tracked) done[dev] = true;
+    }
+    return VCLA_OK;
+}
+
 static inline size_t vcla_dtype_size(int dtype) { return dtype == VCLA_F32 ? 4 : 2; }
 static inline bool vcla_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 

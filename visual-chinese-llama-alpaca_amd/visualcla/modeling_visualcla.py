@@ -166,8 +166,6 @@ class VisualCLAModel:
         path = visualcla_model_name_or_path
         if path is None or not os.path.isdir(path):
             raise ValueError(f"visualcla model path '{path}' is not a local directory (no network access here)")
-        if load_in_8bit:
-            raise ValueError("load_in_8bit (bitsandbytes, CUDA-only) is not available; weights are loaded as bf16")
         config = VisualCLAConfig.from_pretrained(path)
         top = cls._read_checkpoint_dir(path)
         sd = {k: v for k, v in top.items() if k.startswith(("visual_resampler.", "image_projection_layer."))}
@@ -183,6 +181,10 @@ class VisualCLAModel:
                 sd[prefix + k] = v
         model = cls.from_state_dict(config, sd, default_device, torch_dtype)
         model.generation_config = cls._load_generation_config(os.path.join(path, "text_encoder"), config.text_config)
+        if load_in_8bit:
+            # the reference quantises the LLaMA only (bitsandbytes int8, modeling_visualcla.py:151-156); the MI355X analogue is
+            # the OCP fp8 (e4m3fn) weight path on the fp8 MFMA pipe
+            model.enable_fp8_decode()
         return model
 
     @staticmethod
@@ -247,6 +249,8 @@ class VisualCLAModel:
             visualcla_config.text_config["vocab_size"] = sd["text_model.model.embed_tokens.weight"].shape[0]
         model = cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
         model.generation_config = cls._load_generation_config(text_model_name_or_path, visualcla_config.text_config)
+        if load_in_8bit:
+            model.enable_fp8_decode()      # MI355X analogue of bitsandbytes int8 on the LLaMA (modeling_visualcla.py:246-251)
         return model
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -342,14 +346,14 @@ class VisualCLAModel:
             return self
         if image_size % v["patch_size"]:
             raise ValueError(f"image_size {image_size} is not a multiple of the patch size {v['patch_size']}")
-        had_fp8 = self.fp8_decode
-        sd = self.state_dict()
+        # only the position embedding depends on the resolution: interpolate it on the host (the same arithmetic as the oracle /
+        # the reference helper) and swap that one tensor -- every other packed tensor, incl. the fp8 / fragment-major copies, stays
+        key = "vision_model.embeddings.position_embedding.weight"
+        sd = {key: self._packed["vit.pos"].detach().float().cpu()}
         extend_position_embedding(sd, v["patch_size"], image_size)
         v["image_size"] = image_size
         self.vision_model.config.image_size = image_size
-        self._packed = pack_state_dict(sd, self.config, self._device, self._dtype)
-        if had_fp8:
-            add_fp8_copies(self._packed)      # re-packing drops the derived copies
+        self._packed["vit.pos"] = sd[key].to(device=self._device, dtype=torch.float32).contiguous()
         self._ws.clear()
         self._build_ctx()
         return self
@@ -496,6 +500,16 @@ class VisualCLAModel:
             raise ValueError(f"attention_mask length {am.shape[1]} does not match sequence length {T}")
         if bool(am.bool().all()):
             return None
+        # RoPE positions here are absolute sequence indices.  For padding at either END of a row that is what the reference
+        # computes too (a contiguous left pad shifts a row's positions by a constant, which RoPE attention is invariant to); zeros
+        # BETWEEN visible tokens -- only reachable through image_at_head=True with a left-padded text mask,
+        # models/visualcla/modeling_visualcla.py:307-312 -- would put the text at other relative distances from the image tokens
+        # than HF's cumsum(attention_mask) positions do: refuse instead of computing something else.
+        vis = am != 0
+        gap = (~vis) & (vis.int().cummax(dim=1).values > 0)            # a masked position after a visible one ...
+        if bool((vis & (gap.int().cummax(dim=1).values > 0)).any()):   # ... followed by another visible one
+            raise ValueError("attention_mask has masked positions between visible tokens (image_at_head=True with left padding?); "
+                             "only left- or right-padded masks are supported")
         km = torch.ones(B, ctx_max, dtype=torch.int32, device=self._device)
         km[:, :T] = am.to(torch.int32)
         return km

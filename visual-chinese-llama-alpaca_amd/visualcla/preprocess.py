@@ -119,12 +119,20 @@ class GpuClipImageProcessor:
         dev_imgs = images.to(self.device, non_blocking=True).contiguous()
         (h_lo, h_n, h_k, v_lo, v_n, v_k), hk, vk = self._plan(H, W)
         nbytes = N * H * S * 3
-        if getattr(self, "_tmp", None) is None or self._tmp.numel() < nbytes:
-            self._tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)     # grown, never shrunk: no per-call allocation
+        # intermediate of the horizontal pass: one buffer PER STREAM (two calls on different streams must not share it), grown, never
+        # shrunk -- and never freed while a launch may still read it: an outgrown buffer stays referenced until this stream has
+        # passed the event recorded behind its last use (record_stream), so there is no per-call allocation and no cross-stream race
+        tmps = self.__dict__.setdefault("_tmp_by_stream", {})
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        tmp = tmps.get(skey)
+        if tmp is None or tmp.numel() < nbytes:
+            tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            tmp.record_stream(torch.cuda.current_stream(self.device))
+            tmps[skey] = tmp
         mean = (C.c_float * 3)(*self.image_mean)
         std = (C.c_float * 3)(*self.image_std)
         with torch.cuda.device(self.device):
-            _lib.check(lib.vcla_image_preprocess_batch(dev_imgs.data_ptr(), N, H, W, self._tmp.data_ptr(), S, h_lo.data_ptr(), h_n.data_ptr(),
+            _lib.check(lib.vcla_image_preprocess_batch(dev_imgs.data_ptr(), N, H, W, tmp.data_ptr(), S, h_lo.data_ptr(), h_n.data_ptr(),
                                                        h_k.data_ptr(), hk, v_lo.data_ptr(), v_n.data_ptr(), v_k.data_ptr(), vk,
                                                        self.rescale_factor, mean, std, out.data_ptr(), _lib.dtype_code(out.dtype),
                                                        _lib.stream_ptr()))
