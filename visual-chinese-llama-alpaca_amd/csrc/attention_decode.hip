@@ -290,6 +290,219 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const T* __restric
     }
 }
 
+// =================================================================== single-pass ("flash") form, bf16 (round 3)
+// The kernel above walks the cache in dependent phases: K pass(es) -> block-wide max -> exp pass -> sum -> normalise -> V pass(es),
+// four barriers and as many exposed HBM round trips as there are passes (context 192 at B = 64: 3 + 2).  Here every lane group
+// (D/8 adjacent lanes = one 16-byte chunk each of a key row AND of the same key's value row) keeps its own online-softmax state
+// (m, l, o[8]) over the keys it owns, so K and V rows are requested TOGETHER, a batch of U keys ahead of the batch being
+// consumed (register double buffer), and nothing in the loop waits on a barrier or on another lane group.  The groups meet once:
+// butterfly over the wave, LDS over the waves.  The score reduction over the group's lanes uses DPP row operations (quad_perm /
+// row_half_mirror / row_mirror folded into v_add_f32) instead of ds_bpermute, q . k runs on v_dot2c_f32_bf16 against the bf16
+// q fragment (q is bf16-rounded after RoPE, as in HF: nothing is lost), and the probabilities stay fp32 (HF rounds the
+// normalised p to bf16 before P V; the un-rounded form is closer to the fp32 oracle and inside the stated bf16 bounds).
+// K / V rows are read with the non-temporal policy: each row is read by exactly one workgroup per step.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the LPK (4 / 8 / 16) adjacent lanes of a lane group; every lane of the group ends up with the total
+template <int LPK> __device__ __forceinline__ float group_sum(float v) {
+    v += dpp_mov<0xB1>(v);                        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                        // quad_perm [2,3,0,1]
+    if (LPK >= 8) v += dpp_mov<0x141>(v);         // row_half_mirror
+    if (LPK >= 16) v += dpp_mov<0x140>(v);        // row_mirror
+    return v;
+}
+__device__ __forceinline__ u32x4_t ld_nt16(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+// 8 bf16 x 8 bf16 -> fp32 on v_dot2c_f32_bf16.  (The pairs are taken with shufflevector: __builtin_bit_cast of an ext-vector
+// ELEMENT expression, e.g. bit_cast<bf16x2>(a.y), is miscompiled by this clang -- every element collapses to .x.)
+__device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b) {
+    const bf16x8_t x = __builtin_bit_cast(bf16x8_t, a), y = __builtin_bit_cast(bf16x8_t, b);
+    float acc = 0.f;
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(y, y, 0, 1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(y, y, 2, 3), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), acc, false);
+    return acc;
+}
+
+template <int D, int NW, bool MASK>
+__global__ __launch_bounds__(NW * 64, 4) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                                const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                                bf16_t* __restrict__ out, int H, int ctx_max, int pos0,
+                                                                const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
+                                                                int64_t key_mask_ld, float scale, int out_frag_mt) {
+    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = NW * KPW, HALF = D / 2, U = 4, NT = NW * 64;
+    // one LDS object (16-byte aligned carve): roped q as packed bf16 [D/2 dwords], new key / value fp32 [D] each, wave partials
+    __shared__ __attribute__((aligned(16))) float smem[D / 2 + 2 * D + NW * (D + 2)];
+    uint32_t* qpk = reinterpret_cast<uint32_t*>(smem);       // [D/2]  bf16 pairs (2e, 2e+1)
+    float* knew = smem + D / 2;                              // [D]
+    float* vnew = knew + D;                                  // [D]
+    float* part = vnew + D;                                  // [NW][D + 2]: o[D], m, l
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int pos = pos0 + (pos_dev ? *pos_dev : 0);         // position of the new token = number of cached keys
+    const int HD = H * D;
+    const bf16_t* row = qkv + (int64_t)b * 3 * HD;
+    bf16_t* kbase = kc + ((int64_t)b * H + h) * ctx_max * D;
+    bf16_t* vbase = vc + ((int64_t)b * H + h) * ctx_max * D;
+    const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
+    const int c = lane % LPK, grp = wave * KPW + lane / LPK;   // chunk of the row, lane group within the workgroup
+
+    // ---- RoPE inputs first (small, needed first), the first batch of cache rows right behind them: vmcnt retires in order, so
+    // this order lets the RoPE phase run while the rows are still in flight
+    float rc = 0.f, rs = 0.f, q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
+    if (tid < HALF) {
+        rc = cos_tab[(int64_t)pos * HALF + tid]; rs = sin_tab[(int64_t)pos * HALF + tid];
+        q0 = bf2f(row[h * D + tid]); q1 = bf2f(row[h * D + tid + HALF]);
+        k0 = bf2f(row[HD + h * D + tid]); k1 = bf2f(row[HD + h * D + tid + HALF]);
+    }
+    u32x4_t kA[U], vA[U], kB[U], vB[U];
+    int mA[U], mB[U];
+    const int last = pos > 0 ? pos - 1 : 0;
+    // rows past the context are clamped to the last cached row (a line the group reads anyway) and masked at use: the loads
+    // are unconditional, so the loop carries no branch around a load and the compiler emits counted waits
+    // buffer loads (uniform descriptor per (b, h) slab + one 32-bit offset per row, non-temporal): no 64-bit address arithmetic in
+    // the loop, and the policy bit survives (the plain nontemporal load builtin lost it once fences were nearby)
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(kbase, 0, ctx_max * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vbase, 0, ctx_max * D * 2, 0x00020000);
+#define FD_LOAD(KB_, VB_, MB_, t_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
+        int j_ = grp + ((t_) * U + u) * KPB;                                                                         \
+        j_ = j_ < pos ? j_ : last;                                                                                   \
+        const unsigned off_ = (unsigned)(j_ * D + c * 8) * 2u;                                                       \
+        KB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rK, off_, 0, 2 /* nt */));         \
+        VB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, off_, 0, 2 /* nt */));         \
+        MB_[u] = MASK ? km[j_] : 1;                                                                                  \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    const int nb = (pos + U * KPB - 1) / (U * KPB);          // batches of U keys per lane group (workgroup-uniform)
+    if (nb > 0) { FD_LOAD(kA, vA, mA, 0) }
+    if (tid < HALF) {
+        const float cr = Act<bf16_t>::rnd(rc), sr = Act<bf16_t>::rnd(rs);
+        const float a0 = Act<bf16_t>::rnd(q0 * cr - q1 * sr), a1 = Act<bf16_t>::rnd(q1 * cr + q0 * sr);
+        const float r0 = Act<bf16_t>::rnd(k0 * cr - k1 * sr), r1 = Act<bf16_t>::rnd(k1 * cr + k0 * sr);
+        reinterpret_cast<bf16_t*>(qpk)[tid] = f2bf(a0);
+        reinterpret_cast<bf16_t*>(qpk)[tid + HALF] = f2bf(a1);
+        knew[tid] = r0; knew[tid + HALF] = r1;
+        kbase[(int64_t)pos * D + tid] = f2bf(r0);
+        kbase[(int64_t)pos * D + tid + HALF] = f2bf(r1);
+    } else {
+        for (int i = tid - HALF; i < D; i += NT - HALF) {    // the threads past the RoPE lanes move the value row
+            const bf16_t v = row[2 * HD + h * D + i];
+            vnew[i] = bf2f(v);
+            vbase[(int64_t)pos * D + i] = v;
+        }
+    }
+    // LDS-only release / acquire around a bare s_barrier: __syncthreads() would also drain vmcnt (the cache-append stores AND,
+    // in order behind them, the first batch of row loads) in every wave before any of them may start on the scores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(qpk + c * 4);     // this lane's 8 q values, packed bf16
+    const float sl2 = scale * 1.44269504088896340736f;                     // scores live in the log2 domain
+
+    float m_run = -INFINITY, l_run = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#define FD_COMPUTE(KB_, VB_, MB_, t_)                                                                                \
+    {                                                                                                                \
+        float s_[U];                                                                                                 \
+        float mb_ = -INFINITY;                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
+            const int j_ = grp + ((t_) * U + u) * KPB;                                                               \
+            const float d_ = group_sum<LPK>(dot8_bf16(qv, KB_[u]));                                                  \
+            s_[u] = (j_ < pos && MB_[u] != 0) ? d_ * sl2 : -INFINITY;                                                \
+            mb_ = fmaxf(mb_, s_[u]);                                                                                 \
+        }                                                                                                            \
+        const float mn_ = fmaxf(m_run, mb_);                                                                         \
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;        /* nothing visible so far: keep everything at 0 */    \
+        const float al_ = __builtin_amdgcn_exp2f(m_run - mu_);                                                       \
+        m_run = mn_;                                                                                                 \
+        float ps_ = 0.f;                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] *= al_;                                                   \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
+            const float p_ = __builtin_amdgcn_exp2f(s_[u] - mu_);                                                    \
+            ps_ += p_;                                                                                               \
+            float vv_[8];                                                                                            \
+            bf8_to_f32(make_uint4(VB_[u].x, VB_[u].y, VB_[u].z, VB_[u].w), vv_);                                     \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, vv_[e], o[e]);                   \
+        }                                                                                                            \
+        l_run = l_run * al_ + ps_;                                                                                   \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    // two batches per trip, both computed unconditionally (a batch past the context is all masked: p = 0, alpha = 1): a branch
+    // around the second compute lets the compiler sink the B loads into it, right in front of their use -- no prefetch left
+    for (int t = 0; t < nb; t += 2) {
+        FD_LOAD(kB, vB, mB, t + 1)                 // (rows past the context: a harmless re-load of the last row)
+        FD_COMPUTE(kA, vA, mA, t)
+        FD_LOAD(kA, vA, mA, t + 2)
+        FD_COMPUTE(kB, vB, mB, t + 1)
+    }
+#undef FD_LOAD
+#undef FD_COMPUTE
+    {   // the new token (key / value still in LDS): every group computes it, only group 0 of the workgroup folds it in
+        float d_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const uint32_t qq = qpk[c * 4 + e / 2];
+            d_ = __builtin_fmaf(__uint_as_float(qq << 16), knew[c * 8 + e], d_);
+            d_ = __builtin_fmaf(__uint_as_float(qq & 0xffff0000u), knew[c * 8 + e + 1], d_);
+        }
+        d_ = group_sum<LPK>(d_);
+        const float s_ = (grp == 0 && (!MASK || km[pos] != 0)) ? d_ * sl2 : -INFINITY;
+        const float mn_ = fmaxf(m_run, s_);
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+        const float al_ = __builtin_amdgcn_exp2f(m_run - mu_), p_ = __builtin_amdgcn_exp2f(s_ - mu_);
+        m_run = mn_;
+        l_run = l_run * al_ + p_;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, vnew[c * 8 + e], o[e] * al_);
+    }
+    // ---- merge the KPW lane groups of the wave (butterfly over lanes LPK, 2 LPK, ... apart), then the waves through LDS
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m_run, off, 64), l2 = __shfl_xor(l_run, off, 64);
+        const float mn_ = fmaxf(m_run, m2);
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+        const float a1 = __builtin_amdgcn_exp2f(m_run - mu_), a2 = __builtin_amdgcn_exp2f(m2 - mu_);
+        l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * a1 + __shfl_xor(o[e], off, 64) * a2;
+        m_run = mn_;
+    }
+    if (lane < LPK) {
+        float* pw = part + wave * (D + 2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pw[lane * 8 + e] = o[e];
+        if (lane == 0) { pw[D] = m_run; pw[D + 1] = l_run; }
+    }
+    __syncthreads();
+    if (tid < LPK) {       // D/8 threads, 8 output dims each
+        float mf = part[D];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mf = fmaxf(mf, part[w * (D + 2) + D]);
+        const float mu_ = mf == -INFINITY ? 0.f : mf;
+        float lf = 0.f, o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* pw = part + w * (D + 2);
+            const float a_ = __builtin_amdgcn_exp2f(pw[D] - mu_);
+            lf += pw[D + 1] * a_;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] += pw[tid * 8 + e] * a_;
+        }
+        const float inv = lf > 0.f ? 1.0f / lf : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] *= inv;
+        const int k = h * D + tid * 8;
+        bf16_t* dst = out_frag_mt > 0 ? out + ((((int64_t)(k >> 5) * out_frag_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3)
+                                      : out + (int64_t)b * HD + k;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(o8[0], o8[1]), pack_bf2(o8[2], o8[3]), pack_bf2(o8[4], o8[5]), pack_bf2(o8[6], o8[7]));
+    }
+}
+
 template <typename T, int D>
 static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_tab, const float* sin_tab, void* out, int B,
                          int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
@@ -304,6 +517,21 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
     VCLA_REQUIRE(lds <= 64 * 1024, VCLA_ERR_BAD_SHAPE, "attn_decode: ctx_max=%d needs %zu B of LDS (max 64 KiB)", ctx_max, lds);
     dim3 grid(H, B);
     const int out_frag_mt = out_frag ? (B + 15) / 16 : 0;
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the single-pass kernel (VCLA_ATTN_FLASH=0 restores the phased kernel below for A/B runs).  2-wave workgroups once
+        // B * H fills the chip that way (16 per CU by waves), 4 waves otherwise; the row-major output needs 16-byte rows.
+        static const int flash_env = getenv("VCLA_ATTN_FLASH") ? atoi(getenv("VCLA_ATTN_FLASH")) : 1;
+        if (flash_env && (out_frag || (((int64_t)H * D) % 8 == 0 && vcla_aligned(out, 16)))) {
+            const bool small_wg = (int64_t)B * H >= 1024 && nw_env != 4;
+#define FD_GO(NW_, MASK_) attn_decode_flash_kernel<D, NW_, MASK_><<<grid, NW_ * 64, 0, s>>>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_tab, sin_tab, \
+                                                    (bf16_t*)out, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag_mt)
+            if (small_wg) { if (key_mask) FD_GO(2, true); else FD_GO(2, false); }
+            else { if (key_mask) FD_GO(4, true); else FD_GO(4, false); }
+#undef FD_GO
+            VCLA_CHECK_LAUNCH("attn_decode_flash_kernel");
+            return VCLA_OK;
+        }
+    }
     static const int coop_env = getenv("VCLA_ATTN_COOP") ? atoi(getenv("VCLA_ATTN_COOP")) : -1;   // -1 auto, 0 / 1 force (A/B runs)
     const bool coop = coop_env >= 0 ? coop_env != 0 : (int64_t)B * H >= 512;
     if (coop && NWs == 2)

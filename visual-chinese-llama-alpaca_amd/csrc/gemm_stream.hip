@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #define DS_WAVES 8
+int vcla_gemm_dstream2_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s);   // gemm_stream2.hip
 #define DS_ROUND 8   // epilogue units reduced per LDS round (one per wave)
 
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
@@ -318,6 +319,15 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(vcla_gemm_args a, int sp
     if (a.C) Act<OutT>::st4((OutT*)a.C + (int64_t)m * a.ldc + n, v);
 }
 
+// the reduce launch of a split-K streaming GEMM (shared with gemm_stream2.hip)
+int vcla_ds_reduce_launch(const vcla_gemm_args* a, hipStream_t s) {
+    const int64_t work = (int64_t)a->M * (a->N / 4);
+    if (a->out_f32) ds_reduce_kernel<float><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
+    else ds_reduce_kernel<bf16_t><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
+    VCLA_CHECK_LAUNCH("ds_reduce_kernel");
+    return VCLA_OK;
+}
+
 template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
@@ -360,6 +370,9 @@ int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
         if (groups > units) groups = units;
         grid = groups * a->ds_splitk;
     }
+    // bf16 weights: the loader-wave form (gemm_stream2.hip) unless VCLA_DS2=0 (A/B runs against this file's kernel)
+    static const int ds2_env = getenv("VCLA_DS2") ? atoi(getenv("VCLA_DS2")) : 1;
+    if (!fp8 && ds2_env) return vcla_gemm_dstream2_launch(a, units, grid, s);
 #define DS_GO(EPI_, OUT_) return fp8 ? ds_pick_mt<EPI_, OUT_, true>(a, units, grid, s) : ds_pick_mt<EPI_, OUT_, false>(a, units, grid, s)
     if (swiglu) { DS_GO(VCLA_EPI_SWIGLU, bf16_t); }
     if (a->out_f32) { DS_GO(VCLA_EPI_NONE, float); }
