@@ -375,6 +375,12 @@ def main():
                 by = B * H * pos * d * 2 * 2
                 print(f"attndec B={B:3d} ctx={pos:4d}  {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s of K/V rows  ({by/t/8e12*100:5.1f}% of HBM peak)")
             del kcs, vcs
+    if "vitattn" in which:
+        print("== MFMA flash attention, vision shapes; env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_")))
+        bench_attn("vit 224px (B=64)", 64, 16, 257, 257, 64, False, 2)
+        bench_attn("vit 336px (B=32)", 32, 16, 577, 577, 64, False, 2)
+        bench_attn("resampler (B=64)", 64, 16, 64, 321, 64, False, 2)
+        bench_attn("llama prefill (B=64,T=128)", 64, 32, 128, 128, 128, True, 2)
     if "attn" in which:
         print("== attention")
         for fk in (1, 2):

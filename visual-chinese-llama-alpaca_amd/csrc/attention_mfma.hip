@@ -20,6 +20,7 @@
 // LDS: K tile [64][D] bf16 and V^T tile [D][64] bf16, 16-byte chunks XOR-swizzled so every ds_read_b128
 // fragment read is bank-conflict-free.  Next tile is prefetched into registers under the MFMAs.
 #include "vcla_common.h"
+#include <stdlib.h>
 
 #define FA_KV 64
 
@@ -35,15 +36,18 @@ __device__ __forceinline__ int fa_key_pos(int key) {
     return ((t >> 1) << 5) + (g << 3) + ((t & 1) << 2) + r;
 }
 
-template <int D, int NW>
+// DB: K / V^T tiles double-buffered in LDS -- tile t+1 is parked in the other buffer BEFORE the MFMAs of tile t, so a key tile
+// costs ONE barrier instead of two and no wave waits for the staging stores of the others (d = 64: 32 KiB per workgroup, three
+// 9-wave workgroups per CU as before; the d = 128 causal prefill keeps the single buffer -- 64 KiB would halve its occupancy).
+template <int D, int NW, bool DB>
 __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
     constexpr int FA_QB = NW * 32, NT = NW * 64;
     constexpr int KST = D / 32;         // MFMA k-steps over the head dim (Q K^T)
     constexpr int DT = D / 16;          // 16-wide output d tiles (P V)
     constexpr int CH = D / 8;           // 16-byte chunks per K/V row
     constexpr int NLD = (FA_KV * CH + NT - 1) / NT;  // staging loads per thread per operand
-    __shared__ __attribute__((aligned(16))) unsigned char ks[FA_KV * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char vts[D * FA_KV * 2];
+    constexpr int NBUF = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[NBUF * 2 * FA_KV * D * 2];   // [buf][K tile | V^T tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -84,6 +88,12 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
         const int last_q = (q0 + FA_QB < Tq ? q0 + FA_QB : Tq) - 1;
         kv_end = last_q + coff + 1 < Tk ? last_q + coff + 1 : Tk;
     }
+    // Bidirectional sequences here end ONE key past a multiple of 64 (ViT: 257 = 4 x 64 + 1, 577 = 9 x 64 + 1 tokens; resampler: 321 /
+    // 641 keys): as a tile that key would cost a full 64-key tile (20 % of the ViT attention).  Up to 4 such remainder keys are
+    // peeled off the tile loop and folded in after it on the VALU (n_extra below): q . k on v_dot2c against the Q fragments the
+    // lane already holds, one online-softmax update, 4 x DT FMAs into O.  The tile loop then sees whole tiles only (no mask pass).
+    int n_extra = 0;
+    if (!a.causal && !km && Tk > FA_KV && (Tk % FA_KV) >= 1 && (Tk % FA_KV) <= 4) { n_extra = Tk % FA_KV; kv_end = Tk - n_extra; }
     const int ntiles = (kv_end + FA_KV - 1) / FA_KV;
 
     // ---- staging maps
@@ -99,7 +109,9 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kg * a.v_rs + ch * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        unsigned char* ks = lds_all + buf * (2 * FA_KV * D * 2);
+        unsigned char* vts = ks + FA_KV * D * 2;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int id = i * NT + tid, key = id / CH, ch = id % CH;
@@ -114,28 +126,21 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
         }
     };
 
-    if (ntiles > 0) load_tile(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        __syncthreads();  // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
-                                                         // prefetch registers out of scratch
-        const int kv0 = tile * FA_KV;
-        // causal: a wave whose rows all precede this tile has nothing to do here
-        const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
-        if (skip) continue;
-
+    // ---- one key tile of 64 keys against the wave's 32 query rows
+    auto tile_body = [&](int buf, int kv0) {
+        constexpr int NTK = 4, NS = 2;
+        const unsigned char* ks = lds_all + buf * (2 * FA_KV * D * 2);
+        const unsigned char* vts = ks + FA_KV * D * 2;
         // ---- S^T = K Q^T
-        f32x4_t sacc[2][4];
+        f32x4_t sacc[2][NTK];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTK; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < NTK; ++t) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s * 4 + g));
                 sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][s], sacc[0][t], 0, 0, 0);
                 sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][s], sacc[1][t], 0, 0, 0);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
         // flops): the visibility test runs only on tiles that need one (wave-uniform: padding mask, the last tile, the causal
         // diagonal), the row maximum is taken on the raw scores (scale > 0), and scale / max-subtraction are one FMA feeding a raw
         // v_exp_f32.
-        const bool need_mask = km != nullptr || kv0 + FA_KV > Tk || (a.causal && kv0 + FA_KV - 1 > qw + coff);
+        const bool need_mask = km != nullptr || kv0 + NTK * 16 > Tk || (a.causal && kv0 + NTK * 16 - 1 > qw + coff);
         if (need_mask) {
             // key-padding mask of the 64 keys of this tile as a wave-uniform bit mask (one load per lane + ballot)
             unsigned long long tmask = ~0ull;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
                 const int qrow = qw + qt * 16 + ql;
                 const int klim = a.causal ? (qrow + coff < Tk - 1 ? qrow + coff : Tk - 1) : Tk - 1;  // last visible key
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < NTK; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kv0 + t * 16 + g * 4 + r;
@@ -170,12 +175,12 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
                     }
             }
         }
-        bf16x8_t pf[2][2];
+        bf16x8_t pf[2][NS];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < NTK; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
             mx *= sl2;                                   // log2 domain (-inf stays -inf)
@@ -186,9 +191,9 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             const float alpha = exp2f(m_run[qt] - m_use);             // exp2(-inf) = 0 on the first tile
             m_run[qt] = m_new;
             float ps = 0.f;
-            float pv[16];
+            float pv[NTK * 4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < NTK; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][t][r], sl2, -m_use));   // raw v_exp_f32: exp2f() adds denormal-range scaling, ~4 VALU per score
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
             // P^T fragments: key-step s takes S tiles (2s, 2s+1): slots j<4 from tile 2s, j>=4 from tile 2s+1
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 uint4 u;
                 u.x = pack_bf2(pv[(2 * s) * 4 + 0], pv[(2 * s) * 4 + 1]);
                 u.y = pack_bf2(pv[(2 * s) * 4 + 2], pv[(2 * s) * 4 + 3]);
@@ -213,16 +218,84 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vts + fa_vt_off(dt * 16 + ql, s * 32 + g * 8));
                 o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][s], o[0][dt], 0, 0, 0);
                 o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][s], o[1][dt], 0, 0, 0);
             }
         }
+    };
+    auto run_tile = [&](int tile, int buf) {
+        const int kv0 = tile * FA_KV;
+        // causal: a wave whose rows all precede this tile has nothing to do here
+        const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
+        if (skip) return;
+        tile_body(buf, kv0);
+    };
+
+    if (ntiles > 0) load_tile(0);
+    if constexpr (DB) {
+        if (ntiles > 0) {
+            store_tile(0);
+            __syncthreads();
+            load_tile(ntiles > 1 ? 1 : 0);
+        }
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int cur = tile & 1;
+            if (tile + 1 < ntiles) store_tile(cur ^ 1);      // buffer cur^1 was last read before the barrier that ended tile - 1
+            load_tile(tile + 2 < ntiles ? tile + 2 : ntiles - 1);   // unconditional (the last ones are harmless re-loads)
+            run_tile(tile, cur);
+            __syncthreads();
+        }
+    } else {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            __syncthreads();  // previous tile fully consumed
+            store_tile(0);
+            __syncthreads();
+            load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
+                                                             // prefetch registers out of scratch
+            run_tile(tile, 0);
+        }
     }
 
-    // ---- epilogue: O[q][d] = o / l ; lane holds d = dt*16 + g*4 + r for query row qw + qt*16 + ql
     if (!wave_active) return;
+    // ---- remainder keys (see n_extra above): lane (ql, g) holds Q[q][s*32 + g*8 .. +8] -- the K row's same 8-element groups give its
+    // share of q . k (xor 16 / 32 completes the 64 / 128 dims); the lane's O values are d = dt*16 + g*4 + r -> 8 bytes of V per dt.
+    for (int x = 0; x < n_extra; ++x) {
+        const int key = kv_end + x;
+        bf16x8_t kx[KST];
+#pragma unroll
+        for (int s = 0; s < KST; ++s) kx[s] = *reinterpret_cast<const bf16x8_t*>(kb + (int64_t)key * a.k_rs + s * 32 + g * 8);
+        uint2 vx[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vx[dt] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * a.v_rs + dt * 16 + g * 4);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float d_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < KST; ++s) {
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 0, 1), __builtin_shufflevector(kx[s], kx[s], 0, 1), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 2, 3), __builtin_shufflevector(kx[s], kx[s], 2, 3), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 4, 5), __builtin_shufflevector(kx[s], kx[s], 4, 5), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 6, 7), __builtin_shufflevector(kx[s], kx[s], 6, 7), d_, false);
+            }
+            d_ += __shfl_xor(d_, 16, 64);
+            d_ += __shfl_xor(d_, 32, 64);
+            const float sx = d_ * sl2;
+            const float m_new = fmaxf(m_run[qt], sx);              // finite: sx is
+            const float alpha = exp2f(m_run[qt] - m_new), px = __builtin_amdgcn_exp2f(sx - m_new);
+            m_run[qt] = m_new;
+            l_run[qt] = l_run[qt] * alpha + (g == 0 ? px : 0.f);   // l is a per-lane partial, summed over g in the epilogue
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[qt][dt][0] = __builtin_fmaf(px, __uint_as_float(vx[dt].x << 16), o[qt][dt][0] * alpha);
+                o[qt][dt][1] = __builtin_fmaf(px, __uint_as_float(vx[dt].x & 0xffff0000u), o[qt][dt][1] * alpha);
+                o[qt][dt][2] = __builtin_fmaf(px, __uint_as_float(vx[dt].y << 16), o[qt][dt][2] * alpha);
+                o[qt][dt][3] = __builtin_fmaf(px, __uint_as_float(vx[dt].y & 0xffff0000u), o[qt][dt][3] * alpha);
+            }
+        }
+    }
+    // ---- epilogue: O[q][d] = o / l ; lane holds d = dt*16 + g*4 + r for query row qw + qt*16 + ql
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         float l = l_run[qt];
@@ -263,10 +336,14 @@ int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : ((a->Tq > 128 && (int64_t)a->B * a->H >= 256) ? 9 : 4);
     if (nw_env == 4) nw = 4;
     dim3 grid((a->Tq + nw * 32 - 1) / (nw * 32), a->H, a->B);
-    if (a->D == 128) attn_mfma_kernel<128, 4><<<grid, 256, 0, s>>>(*a);
-    else if (nw == 9) attn_mfma_kernel<64, 9><<<grid, 576, 0, s>>>(*a);
-    else if (nw == 2) attn_mfma_kernel<64, 2><<<grid, 128, 0, s>>>(*a);
-    else attn_mfma_kernel<64, 4><<<grid, 256, 0, s>>>(*a);
+    static const int db_env = getenv("VCLA_ATTN_MFMA_DB") ? atoi(getenv("VCLA_ATTN_MFMA_DB")) : 1;   // A/B runs: 0 = single LDS buffer, two barriers per tile
+    if (a->D == 128) attn_mfma_kernel<128, 4, false><<<grid, 256, 0, s>>>(*a);
+    else if (nw == 9 && db_env) attn_mfma_kernel<64, 9, true><<<grid, 576, 0, s>>>(*a);
+    else if (nw == 9) attn_mfma_kernel<64, 9, false><<<grid, 576, 0, s>>>(*a);
+    else if (nw == 2 && db_env) attn_mfma_kernel<64, 2, true><<<grid, 128, 0, s>>>(*a);
+    else if (nw == 2) attn_mfma_kernel<64, 2, false><<<grid, 128, 0, s>>>(*a);
+    else if (db_env) attn_mfma_kernel<64, 4, true><<<grid, 256, 0, s>>>(*a);
+    else attn_mfma_kernel<64, 4, false><<<grid, 256, 0, s>>>(*a);
     VCLA_CHECK_LAUNCH("attn_mfma_kernel");
     return VCLA_OK;
 }

@@ -37,9 +37,12 @@ typedef volatile __attribute__((address_space(3))) unsigned* d2_ctr_ptr_t;
 typedef const __attribute__((address_space(3))) bf16x8_t* d2_frag_ptr_t;
 
 constexpr int d2_wdepth(int NT) { return NT >= 6 ? 4 : (NT >= 4 ? 6 : (NT == 3 ? 8 : (NT == 2 ? 12 : 16))); }
-// ring slots per compute wave: 6 waves x DA x MT KiB <= 120 KiB (the reduction slab, 48 KiB or 96 KiB for SwiGLU, aliases it)
-constexpr int d2_adepth(int MT) { return MT >= 4 ? 5 : (MT == 3 ? 6 : 8); }
-constexpr int d2_inflight(int MT) { return MT >= 4 ? 8 : (MT == 3 ? 10 : 12); }   // loader: stages in flight, MT x this <= 48 DMA instructions
+// ring slots per compute wave: 6 waves x DA x MT KiB <= 144 KiB (the reduction slab, 48 KiB or 96 KiB for SwiGLU, aliases it)
+// (first cut: 5 slots / 8 stages in flight at MT = 4 = 64 KiB of activations in flight per CU -- slower than gemm_stream.hip on
+// every shape: an L2 "hit" is ~2 us away under the weight stream, so 64 KiB in flight is ~32 GB/s per CU, and the activations,
+// not the weights, set the pace.  Now: the largest ring LDS holds and as many DMA instructions in flight as vmcnt counts.)
+constexpr int d2_adepth(int MT) { return MT >= 4 ? 6 : (MT == 3 ? 8 : (MT == 2 ? 12 : 16)); }
+constexpr int d2_inflight(int MT) { return MT >= 4 ? 15 : (MT == 3 ? 20 : (MT == 2 ? 30 : 40)); }   // loader: stages in flight, MT x this <= 60 DMA instructions (vmcnt counts to 63)
 
 struct D2Ctx {
     __amdgpu_buffer_rsrc_t rW;
