@@ -173,6 +173,17 @@ def main():
                 t = timeit(lambda: _lib.gemm(a, w, N, bias=bias, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws))
                 tf = 2.0 * Mv * N * K / t / 1e12
                 print(f"vit   {tag:4s} {nm} M={Mv} N={N:5d} K={K:5d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:.1f}% of peak)")
+    if "vittail" in which:
+        print("== the 64-row ragged-M tail of the ViT GEMMs at B=64: split-K panel + reduce (8) vs skinny, one launch (7)")
+        skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+        for tag, N, K, epi in (("qkv", 3072, 1024, 0), ("out", 1024, 1024, 0), ("fc1", 4096, 1024, 1), ("fc2", 1024, 4096, 0)):
+            a, w = rnd(64, K), packw(N, K)
+            bias = torch.randn(N, device=DEV)
+            out = torch.empty(64, N, dtype=torch.bfloat16, device=DEV)
+            res = rnd(64, N) if tag in ("out", "fc2") else None
+            for fk in (8, 7):
+                t = timeit(lambda: _lib.gemm(a, w, N, bias=bias, epilogue=epi, out=out, residual=res, force_kernel=fk, splitk_ws=skws), reps=50)
+                print(f"vittail {tag:4s} kernel {fk} M=64 N={N:5d} K={K:5d}  {t*1e6:8.1f} us")
     if "skinny" in which:
         print("== skinny (k7) / panel split-K (k8) MFMA GEMM, W streamed once, rotating 4 weight buffers")
         skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)

@@ -326,12 +326,15 @@ __device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b) {
 }
 
 template <int D, int NW, bool MASK>
-__global__ __launch_bounds__(NW * 64, 4) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                                 const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                                 bf16_t* __restrict__ out, int H, int ctx_max, int pos0,
                                                                 const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
                                                                 int64_t key_mask_ld, float scale, int out_frag_mt) {
-    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = NW * KPW, HALF = D / 2, U = 4, NT = NW * 64;
+    // U keys per lane group and batch.  The 2-wave form (batch decode: thousands of workgroups, 4 waves per SIMD) keeps 2 x 4 rows of K
+    // and V per lane in flight; the 4-wave form (a few dozen latency-bound workgroups: B = 1) 2 x 8 -- with D = 128 its 16 groups
+    // then have the first 256 keys of the context requested before the RoPE phase ends
+    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = NW * KPW, HALF = D / 2, U = NW == 2 ? 4 : 8, NT = NW * 64;
     // one LDS object (16-byte aligned carve): roped q as packed bf16 [D/2 dwords], new key / value fp32 [D] each, wave partials
     __shared__ __attribute__((aligned(16))) float smem[D / 2 + 2 * D + NW * (D + 2)];
     uint32_t* qpk = reinterpret_cast<uint32_t*>(smem);       // [D/2]  bf16 pairs (2e, 2e+1)
@@ -376,7 +379,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_decode_flash_kernel(const bf1
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);
     const int nb = (pos + U * KPB - 1) / (U * KPB);          // batches of U keys per lane group (workgroup-uniform)
-    if (nb > 0) { FD_LOAD(kA, vA, mA, 0) }
+    if (nb > 0) {            // the first TWO batches go out ahead of the RoPE arithmetic
+        FD_LOAD(kA, vA, mA, 0)
+        FD_LOAD(kB, vB, mB, 1)
+    }
     if (tid < HALF) {
         const float cr = Act<bf16_t>::rnd(rc), sr = Act<bf16_t>::rnd(rs);
         const float a0 = Act<bf16_t>::rnd(q0 * cr - q1 * sr), a1 = Act<bf16_t>::rnd(q1 * cr + q0 * sr);
@@ -433,10 +439,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_decode_flash_kernel(const bf1
     // two batches per trip, both computed unconditionally (a batch past the context is all masked: p = 0, alpha = 1): a branch
     // around the second compute lets the compiler sink the B loads into it, right in front of their use -- no prefetch left
     for (int t = 0; t < nb; t += 2) {
-        FD_LOAD(kB, vB, mB, t + 1)                 // (rows past the context: a harmless re-load of the last row)
         FD_COMPUTE(kA, vA, mA, t)
-        FD_LOAD(kA, vA, mA, t + 2)
+        FD_LOAD(kA, vA, mA, t + 2)                 // (rows past the context: a harmless re-load of the last row)
         FD_COMPUTE(kB, vB, mB, t + 1)
+        FD_LOAD(kB, vB, mB, t + 3)
     }
 #undef FD_LOAD
 #undef FD_COMPUTE

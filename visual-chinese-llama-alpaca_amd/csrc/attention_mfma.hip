@@ -14,10 +14,11 @@
 //       -> lane holds O[q][d = dt*16 + g*4 + r]: 4 consecutive d of one query row (8-byte stores), and the
 //          online-softmax rescale is a per-lane scalar.
 // The MFMA k-slots of the PV product are whatever keys the lane already holds: k-slot (g, j) of key-step s is key
-// (2s + j/4)*16 + g*4 + j%4.  V^T is written to LDS with that key permutation, so P never moves between lanes.
+// (2s + j/4)*16 + g*4 + j%4.  The V fragments are fetched in exactly that key order (LDS transpose reads, below), so P never moves
+// between lanes.
 // Row max / row sum need only 2 cross-lane steps (xor 16, xor 32).
 //
-// LDS: K tile [64][D] bf16 and V^T tile [D][64] bf16, 16-byte chunks XOR-swizzled so every ds_read_b128
+// LDS: K tile [64][D] bf16 and V tile [64][D] bf16 (both row-major), 16-byte chunks XOR-swizzled so every ds_read_b128
 // fragment read is bank-conflict-free.  Next tile is prefetched into registers under the MFMAs.
 #include "vcla_common.h"
 #include <stdlib.h>
@@ -28,26 +29,30 @@ template <int D> __device__ __forceinline__ int fa_k_off(int key, int ch) {
     if (D == 128) return key * 256 + ((ch ^ (key & 15)) << 4);
     return key * 128 + ((ch ^ ((key >> 1) & 7)) << 4);
 }
-// byte offset of element (row d, key position p) in the V^T tile ([D][64] bf16, 128-byte rows)
-__device__ __forceinline__ int fa_vt_off(int d, int p) { return d * 128 + ((((p >> 3) ^ ((d >> 1) & 7))) << 4) + ((p & 7) << 1); }
-// position of key (0..63) inside the permuted V^T row
-__device__ __forceinline__ int fa_key_pos(int key) {
-    const int t = key >> 4, g = (key >> 2) & 3, r = key & 3;
-    return ((t >> 1) << 5) + (g << 3) + ((t & 1) << 2) + r;
+// V tile: ROW-major [64 keys][D] bf16 (round 3; was V^T with 2-byte scatter stores).  The P V product wants V^T rows as its A operand
+// -- 8 keys of one d per lane -- which gfx950's LDS transpose read delivers straight from the row-major image:
+// ds_read_b64_tr_b16, per 16-lane group, lane i supplies the address of piece (row i / 4, 8 bytes i % 4) of a 4-row x 16-column
+// block and receives COLUMN i of those 4 rows (measured: tools/debug/probe_tr16.py).  Rows = 4 consecutive keys, columns = the 16
+// d of an output tile: two such reads give the 8 k-slots (g, j) = keys (2s + j/4)*16 + g*4 + j%4 of a key step, so P still never
+// moves between lanes and V is staged with ONE 16-byte store per chunk instead of eight 2-byte ones (the V^T scatter was 4-way
+// bank-conflicted and, at 8 stores x 9 waves x 4 tiles, the busiest thing on the CU).  32-byte column blocks are XOR-swizzled with
+// key bits 1-2 so that the 8 rows a 32-lane half touches (128 B apart = same banks 2 rows apart) land on different banks.
+template <int D> __device__ __forceinline__ int fa_v_off(int key, int d) {   // byte offset of element (key, d); d % 4 == 0 for the tr reads
+    constexpr int CB = D / 16;                                                // 32-byte column blocks per row
+    const int f = D == 128 ? key : key >> 1;       // rows 256 B apart share every bank; rows 128 B apart share them two rows on
+    return key * (D * 2) + ((((d >> 4) ^ f) & (CB - 1)) << 5) + ((d & 15) << 1);
 }
+typedef __attribute__((ext_vector_type(4))) short fa_s16x4_t;
+typedef __attribute__((address_space(3))) fa_s16x4_t* fa_lds_v4_t;
 
-// DB: K / V^T tiles double-buffered in LDS -- tile t+1 is parked in the other buffer BEFORE the MFMAs of tile t, so a key tile
-// costs ONE barrier instead of two and no wave waits for the staging stores of the others (d = 64: 32 KiB per workgroup, three
-// 9-wave workgroups per CU as before; the d = 128 causal prefill keeps the single buffer -- 64 KiB would halve its occupancy).
-template <int D, int NW, bool DB>
+template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
     constexpr int FA_QB = NW * 32, NT = NW * 64;
     constexpr int KST = D / 32;         // MFMA k-steps over the head dim (Q K^T)
     constexpr int DT = D / 16;          // 16-wide output d tiles (P V)
     constexpr int CH = D / 8;           // 16-byte chunks per K/V row
     constexpr int NLD = (FA_KV * CH + NT - 1) / NT;  // staging loads per thread per operand
-    constexpr int NBUF = DB ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[NBUF * 2 * FA_KV * D * 2];   // [buf][K tile | V^T tile]
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[2 * FA_KV * D * 2];   // [K tile | V tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -109,28 +114,23 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kg * a.v_rs + ch * 8);
         }
     };
-    auto store_tile = [&](int buf) {
-        unsigned char* ks = lds_all + buf * (2 * FA_KV * D * 2);
+    auto store_tile = [&]() {
+        unsigned char* ks = lds_all;
         unsigned char* vts = ks + FA_KV * D * 2;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int id = i * NT + tid, key = id / CH, ch = id % CH;
             if (id >= FA_KV * CH) continue;
             *reinterpret_cast<u32x4_t*>(ks + fa_k_off<D>(key, ch)) = rk[i];
-            const int p = fa_key_pos(key);
-            auto put2 = [&](uint32_t w, int e) {  // two adjacent d values of one key -> rows d, d+1 of V^T
-                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e, p)) = (bf16_t)(w & 0xffffu);
-                *reinterpret_cast<bf16_t*>(vts + fa_vt_off(ch * 8 + e + 1, p)) = (bf16_t)(w >> 16);
-            };
-            put2(rv[i].x, 0); put2(rv[i].y, 2); put2(rv[i].z, 4); put2(rv[i].w, 6);
+            *reinterpret_cast<u32x4_t*>(vts + fa_v_off<D>(key, ch * 8)) = rv[i];
         }
     };
 
     // ---- one key tile of 64 keys against the wave's 32 query rows
-    auto tile_body = [&](int buf, int kv0) {
+    auto tile_body = [&](int kv0) {
         constexpr int NTK = 4, NS = 2;
-        const unsigned char* ks = lds_all + buf * (2 * FA_KV * D * 2);
-        const unsigned char* vts = ks + FA_KV * D * 2;
+        const unsigned char* ks = lds_all;
+        const auto fa_lds_base = (__attribute__((address_space(3))) unsigned char*)lds_all + FA_KV * D * 2;   // the V tile, as an LDS pointer
         // ---- S^T = K Q^T
         f32x4_t sacc[2][NTK];
 #pragma unroll
@@ -219,43 +219,35 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vts + fa_vt_off(dt * 16 + ql, s * 32 + g * 8));
+                // lane (ql, g): piece (key row ql / 4, 8 bytes ql % 4) of the 4-key x 16-d blocks of S tiles 2s and 2s + 1
+                const int kr = g * 4 + (ql >> 2), dc = dt * 16 + (ql & 3) * 4;
+                const fa_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(fa_lds_base + fa_v_off<D>((2 * s) * 16 + kr, dc)));
+                const fa_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(fa_lds_base + fa_v_off<D>((2 * s + 1) * 16 + kr, dc)));
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
                 o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][s], o[0][dt], 0, 0, 0);
                 o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][s], o[1][dt], 0, 0, 0);
             }
         }
     };
-    auto run_tile = [&](int tile, int buf) {
+    auto run_tile = [&](int tile) {
         const int kv0 = tile * FA_KV;
         // causal: a wave whose rows all precede this tile has nothing to do here
         const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
         if (skip) return;
-        tile_body(buf, kv0);
+        tile_body(kv0);
     };
 
+    // (Measured and dropped, profiles/r03_*: both tiles double-buffered in LDS so that a key tile costs one barrier instead of two --
+    // 58.3 -> 62.3 us for the ViT at B = 64, 23.0 -> 25.4 us for the resampler: the second buffer's LDS costs more co-residency
+    // than the barrier it removes.)
     if (ntiles > 0) load_tile(0);
-    if constexpr (DB) {
-        if (ntiles > 0) {
-            store_tile(0);
-            __syncthreads();
-            load_tile(ntiles > 1 ? 1 : 0);
-        }
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const int cur = tile & 1;
-            if (tile + 1 < ntiles) store_tile(cur ^ 1);      // buffer cur^1 was last read before the barrier that ended tile - 1
-            load_tile(tile + 2 < ntiles ? tile + 2 : ntiles - 1);   // unconditional (the last ones are harmless re-loads)
-            run_tile(tile, cur);
-            __syncthreads();
-        }
-    } else {
-        for (int tile = 0; tile < ntiles; ++tile) {
-            __syncthreads();  // previous tile fully consumed
-            store_tile(0);
-            __syncthreads();
-            load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
-                                                             // prefetch registers out of scratch
-            run_tile(tile, 0);
-        }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
+                                                         // prefetch registers out of scratch
+        run_tile(tile);
     }
 
     if (!wave_active) return;
@@ -336,14 +328,10 @@ int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : ((a->Tq > 128 && (int64_t)a->B * a->H >= 256) ? 9 : 4);
     if (nw_env == 4) nw = 4;
     dim3 grid((a->Tq + nw * 32 - 1) / (nw * 32), a->H, a->B);
-    static const int db_env = getenv("VCLA_ATTN_MFMA_DB") ? atoi(getenv("VCLA_ATTN_MFMA_DB")) : 1;   // A/B runs: 0 = single LDS buffer, two barriers per tile
-    if (a->D == 128) attn_mfma_kernel<128, 4, false><<<grid, 256, 0, s>>>(*a);
-    else if (nw == 9 && db_env) attn_mfma_kernel<64, 9, true><<<grid, 576, 0, s>>>(*a);
-    else if (nw == 9) attn_mfma_kernel<64, 9, false><<<grid, 576, 0, s>>>(*a);
-    else if (nw == 2 && db_env) attn_mfma_kernel<64, 2, true><<<grid, 128, 0, s>>>(*a);
-    else if (nw == 2) attn_mfma_kernel<64, 2, false><<<grid, 128, 0, s>>>(*a);
-    else if (db_env) attn_mfma_kernel<64, 4, true><<<grid, 256, 0, s>>>(*a);
-    else attn_mfma_kernel<64, 4, false><<<grid, 256, 0, s>>>(*a);
+    if (a->D == 128) attn_mfma_kernel<128, 4><<<grid, 256, 0, s>>>(*a);
+    else if (nw == 9) attn_mfma_kernel<64, 9><<<grid, 576, 0, s>>>(*a);
+    else if (nw == 2) attn_mfma_kernel<64, 2><<<grid, 128, 0, s>>>(*a);
+    else attn_mfma_kernel<64, 4><<<grid, 256, 0, s>>>(*a);
     VCLA_CHECK_LAUNCH("attn_mfma_kernel");
     return VCLA_OK;
 }

@@ -604,13 +604,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         // tiles.  Measured at M = 64 (tools/bench_kernels.py dstream): down_proj 33.2 -> 25.7 us with 4 slices, o_proj 15.7 -> 15.0
         // with 2 (4: 15.8); at M = 32 only down_proj gains (24.4 -> 21.6 us).
         static const int sk_env = getenv("VCLA_DS_SPLITK") ? atoi(getenv("VCLA_DS_SPLITK")) : 4;
-        // o_proj: the loader-wave kernel (gemm_stream2.hip, VCLA_DS2, bf16 weights) streams it unsplit -- no fp32 partials, no
-        // reduce launch; the round-2 kernel (and the fp8 weight form) keeps its two K slices.  VCLA_DS_SPLITK_O overrides.
-        static const int ds2_env = getenv("VCLA_DS2") ? atoi(getenv("VCLA_DS2")) : 1;
-        static const int sko_env = getenv("VCLA_DS_SPLITK_O") ? atoi(getenv("VCLA_DS_SPLITK_O")) : -1;
-        const bool ds2 = ds2_env && !(ctx->run.decode_step && L.vo.q8f && L.vo.s8);
-        const int sk_o_auto = ds2 ? 0 : ((M > 32 && D >= 2048 && sk_env > 1) ? 2 : 0);
-        const int sk_o = sko_env >= 0 ? (sko_env > 1 ? sko_env : 0) : sk_o_auto, sk_d = (M > 16 && c.t_inter >= 4096) ? sk_env : 0;
+        const int sk_o = (M > 32 && D >= 2048 && sk_env > 1) ? 2 : 0, sk_d = (M > 16 && c.t_inter >= 4096) ? sk_env : 0;
         const float scale_ = 1.0f / sqrtf((float)d);
         if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
         RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,

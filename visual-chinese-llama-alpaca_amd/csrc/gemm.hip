@@ -1516,6 +1516,8 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                     tail.C = (char*)a->C + (size_t)head.M * a->ldc * cs;
                     if (a->residual) tail.residual = (const char*)a->residual + (size_t)head.M * a->ldr * es;
                     head.force_kernel = 4;
+                    static const int tail_env = getenv("VCLA_TAIL_KERNEL") ? atoi(getenv("VCLA_TAIL_KERNEL")) : 0;   // A/B: 7 = skinny (one launch)
+                    if (tail_env == 7 && rem <= 128 && !a->post_norm_gamma) tail.force_kernel = 7;
                     head.post_norm_gamma = tail.post_norm_gamma = nullptr;   // the wrapper normalises all of C afterwards
                     int rc = gemm_impl(&head, dtype, stream);
                     return rc ? rc : gemm_impl(&tail, dtype, stream);

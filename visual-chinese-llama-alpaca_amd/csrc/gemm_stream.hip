@@ -23,7 +23,6 @@
 #include <stdlib.h>
 
 #define DS_WAVES 8
-int vcla_gemm_dstream2_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s);   // gemm_stream2.hip
 #define DS_ROUND 8   // epilogue units reduced per LDS round (one per wave)
 
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
@@ -38,9 +37,9 @@ __device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 // ring depth: as many stages in flight as fit a ~200-register budget next to the accumulators (acc = NT*MT*4 registers,
 // a stage = (KS*MT + NT)*4), a power of two where possible (K / 256 stages per wave is a power of two for K = 4096: the peeled
 // tail then issues no loads), at most 4
-constexpr int ds_depth(int MT, int NT, bool FP8, int WV = 8) {
+constexpr int ds_depth(int MT, int NT, bool FP8) {
     const int acc = NT * MT * 4, st = ((FP8 ? 2 : 1) * MT + NT) * 4;
-    const int d = ((WV > 8 ? 92 : (FP8 ? 176 : 200)) - acc) / st;   // fp8: the in-register conversion needs temporaries; 16 waves: 128 registers each
+    const int d = ((FP8 ? 176 : 200) - acc) / st;   // fp8: the in-register conversion needs temporaries
     return d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1));   // 4 stages x 8 waves already keep > 100 KiB per CU in flight
 }
 
@@ -63,7 +62,7 @@ struct DsCtx {
 // partial sums, xor-shuffle tree).  The result lands in LDS; the reduction's barrier publishes it to the other waves.
 __device__ __forceinline__ void ds_row_rstd(const vcla_gemm_args& a, const DsCtx& c, float* rstd_s) {
     const int parts = a.a_row_ssq_parts;
-    const int r = c.wave * 8 + (c.lane >> 3), seg = c.lane & 7;     // (waves 8 .. 15 of a 16-wave workgroup: r >= 64, nothing to do)
+    const int r = c.wave * 8 + (c.lane >> 3), seg = c.lane & 7;
     float q = 0.f;
     if (r < a.M) {
         const float* src = a.a_row_ssq + (int64_t)r * parts;
@@ -87,11 +86,11 @@ __device__ __forceinline__ void ds_row_rstd(const vcla_gemm_args& a, const DsCtx
 
 // One chunk of NT weight tiles [c0, c0 + NT) x all rows, K stages wave, wave + 8, ... of this wave; then the cross-wave reduction
 // and the epilogue.  MT = 16-row tiles of A; FP8: W_q8_frag (two k-steps per 16-byte lane load) instead of W_frag.
-template <int EPI, typename OutT, int MT, int NT, bool FP8, int WV = DS_WAVES>
+template <int EPI, typename OutT, int MT, int NT, bool FP8>
 __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, float* rstd_s, bool first) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;       // tiles per epilogue unit (SwiGLU: gate tile + up tile)
     constexpr int KS = FP8 ? 2 : 1;
-    constexpr int D = ds_depth(MT, NT, FP8, WV);
+    constexpr int D = ds_depth(MT, NT, FP8);
     static_assert(NT % TPU == 0, "SwiGLU chunks hold whole gate/up pairs");
     f32x4_t acc[NT][MT];
 #pragma unroll
@@ -105,7 +104,7 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
     // stage t of this wave = global stage ks = wave + 8 t
 #define DS_LOAD(s_, t_)                                                                                         \
     {                                                                                                           \
-        const unsigned ks_ = (unsigned)(c.s_beg + c.wave + WV * (t_));                                          \
+        const unsigned ks_ = (unsigned)(c.s_beg + c.wave + DS_WAVES * (t_));                                    \
         const unsigned ao_ = ks_ * c.a_stage_bytes, wo_ = w_chunk_off + (ks_ << 10);                            \
         _Pragma("unroll") for (int q = 0; q < KS; ++q)                                                          \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
@@ -185,7 +184,7 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
 #pragma unroll
             for (int tt = 0; tt < TPU; ++tt) sum[0][tt] = slab[((0 * DS_ROUND + c.wave) * TPU + tt) * 64 + c.lane];
 #pragma unroll
-            for (int w2 = 1; w2 < WV; ++w2)
+            for (int w2 = 1; w2 < DS_WAVES; ++w2)
 #pragma unroll
                 for (int tt = 0; tt < TPU; ++tt) {
                     const f32x4_t p = slab[((w2 * DS_ROUND + c.wave) * TPU + tt) * 64 + c.lane];
@@ -214,15 +213,13 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
 
 // A workgroup walks its share of tiles in chunks of at most 4 tiles (6 = three gate/up pairs for SwiGLU); every chunk size has
 // its own branch-free instantiation of the loop.
-// WV = waves per workgroup: 8, or 16 for launches whose workgroups own at most 2 tiles (o_proj / down_proj: NT <= 2 leaves 4 - 8
-// KiB of weights in flight per wave -- twice the waves at half the registers double the bytes in flight per CU)
-template <int EPI, typename OutT, int MT, bool FP8, int WV = DS_WAVES>
-__global__ __launch_bounds__(WV * 64) void gemm_dstream_kernel(vcla_gemm_args a, int units_total) {
+template <int EPI, typename OutT, int MT, bool FP8>
+__global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_args a, int units_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ds_smem[];
     f32x4_t* slab = reinterpret_cast<f32x4_t*>(ds_smem);      // [wave][unit in round][tile of unit][lane]
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
-    float* rstd_s = reinterpret_cast<float*>(ds_smem + (size_t)WV * DS_ROUND * TPU * 64 * sizeof(f32x4_t));   // [64] behind the slabs
-    constexpr int NTW = EPI == VCLA_EPI_SWIGLU ? 6 : (WV > 8 ? 2 : 4);
+    float* rstd_s = reinterpret_cast<float*>(ds_smem + (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t));   // [64] behind the slabs
+    constexpr int NTW = EPI == VCLA_EPI_SWIGLU ? 6 : 4;
     constexpr int KS = FP8 ? 2 : 1;
     DsCtx c;
     c.lane = threadIdx.x & 63;
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(WV * 64) void gemm_dstream_kernel(vcla_gemm_args a,
     const int KST = a.K / (32 * KS);                           // stages along K
     c.s_beg = (int)((int64_t)c.ks * KST / S);
     const int s_len = (int)((int64_t)(c.ks + 1) * KST / S) - c.s_beg;
-    c.nst = (s_len - c.wave + WV - 1) / WV;                    // stages of this wave inside the slice: s_beg + wave + WV t
+    c.nst = (s_len - c.wave + DS_WAVES - 1) / DS_WAVES;        // stages of this wave inside the slice: s_beg + wave + 8 t
     c.mt_c = (a.M + 15) >> 4;                                  // == MT (the launcher instantiates MT = ceil(M/16))
     const int n_pad = (a.N + 127) / 128 * 128;
     c.w_tile_bytes = (unsigned)a.K * (FP8 ? 16u : 32u);
@@ -249,9 +246,6 @@ __global__ __launch_bounds__(WV * 64) void gemm_dstream_kernel(vcla_gemm_args a,
             if (nt == 6) ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
-        } else if constexpr (WV > 8) {
-            if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8, WV>(c, c0, slab, rstd_s, c0 == t_beg);
-            else ds_chunk<EPI, OutT, MT, 1, FP8, WV>(c, c0, slab, rstd_s, c0 == t_beg);
         } else {
             if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
@@ -324,23 +318,14 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(vcla_gemm_args a, int sp
     if (a.C) Act<OutT>::st4((OutT*)a.C + (int64_t)m * a.ldc + n, v);
 }
 
-// the reduce launch of a split-K streaming GEMM (shared with gemm_stream2.hip)
-int vcla_ds_reduce_launch(const vcla_gemm_args* a, hipStream_t s) {
-    const int64_t work = (int64_t)a->M * (a->N / 4);
-    if (a->out_f32) ds_reduce_kernel<float><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
-    else ds_reduce_kernel<bf16_t><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
-    VCLA_CHECK_LAUNCH("ds_reduce_kernel");
-    return VCLA_OK;
-}
-
-template <int EPI, typename OutT, int MT, bool FP8, int WV = DS_WAVES>
+template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
-    const size_t lds = (size_t)WV * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU / 16 waves) + rstd[64]
-    auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8, WV>;
+    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU) + rstd[64]
+    auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
-    kern<<<grid, WV * 64, lds, s>>>(*a, units);
+    kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
     VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
     if constexpr (EPI == VCLA_EPI_NONE) {
         if (a->ds_splitk > 1) {
@@ -355,12 +340,6 @@ static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s
 template <int EPI, typename OutT, bool FP8>
 static int ds_pick_mt(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     const int mt = (a->M + 15) / 16;
-    if constexpr (EPI == VCLA_EPI_NONE && !FP8) {
-        // 16-wave workgroups when every workgroup owns <= 2 tiles (o_proj / down_proj at one workgroup per CU): VCLA_DS_W16=1
-        static const int w16_env = getenv("VCLA_DS_W16") ? atoi(getenv("VCLA_DS_W16")) : 0;
-        const int groups = a->ds_splitk > 1 ? grid / a->ds_splitk : grid;
-        if (w16_env && mt == 4 && (units + groups - 1) / groups <= 2) return ds_launch<EPI, OutT, 4, FP8, 16>(a, units, grid, s);
-    }
     if (mt <= 1) return ds_launch<EPI, OutT, 1, FP8>(a, units, grid, s);
     if (mt == 2) return ds_launch<EPI, OutT, 2, FP8>(a, units, grid, s);
     if (mt == 3) return ds_launch<EPI, OutT, 3, FP8>(a, units, grid, s);
@@ -381,9 +360,6 @@ int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
         if (groups > units) groups = units;
         grid = groups * a->ds_splitk;
     }
-    // bf16 weights: the loader-wave form (gemm_stream2.hip) unless VCLA_DS2=0 (A/B runs against this file's kernel)
-    static const int ds2_env = getenv("VCLA_DS2") ? atoi(getenv("VCLA_DS2")) : 1;
-    if (!fp8 && ds2_env) return vcla_gemm_dstream2_launch(a, units, grid, s);
 #define DS_GO(EPI_, OUT_) return fp8 ? ds_pick_mt<EPI_, OUT_, true>(a, units, grid, s) : ds_pick_mt<EPI_, OUT_, false>(a, units, grid, s)
     if (swiglu) { DS_GO(VCLA_EPI_SWIGLU, bf16_t); }
     if (a->out_f32) { DS_GO(VCLA_EPI_NONE, float); }
