@@ -157,6 +157,22 @@ def test_bad_history_and_missing_path_errors(loaded):
                                                         device_map=None, load_in_8bit=False)
 
 
+def test_load_in_8bit_selects_the_fp8_weight_path(tmp_path):
+    """the reference's `load_in_8bit=True` (bitsandbytes int8 on the LLaMA, modeling_visualcla.py:151-156) maps onto the fp8
+    weight copies (W8A16: fp8 weights, bf16 activations) instead of raising; chat() runs on them"""
+    import visualcla
+    cfg = _tiny_cfg()
+    W = O.make_weights(cfg, seed=0)
+    path = make_merged_dir(str(tmp_path / "merged8"), cfg, W)
+    model, tokenizer, image_processor = visualcla.get_model_and_tokenizer_and_processor(
+        visualcla_model=path, torch_dtype=torch.float16, default_device="cuda:0", load_in_8bit=True)
+    assert model.fp8_decode and not getattr(model, "_fp8_mfma", False)
+    from transformers import GenerationConfig
+    resp, hist = visualcla.chat(model, _image(), "what is in the image?", history=[],
+                                generation_config=GenerationConfig(max_new_tokens=4, do_sample=False))
+    assert isinstance(resp, str) and len(hist) == 2
+
+
 def test_gpu_preprocess_gives_the_same_chat(loaded, tmp_path):
     """next row N1: the loader's gpu_preprocess=True processor feeds the same pixels, so chat() answers identically"""
     from transformers import GenerationConfig

@@ -45,14 +45,19 @@ template <int D> __device__ __forceinline__ int fa_v_off(int key, int d) {   // 
 typedef __attribute__((ext_vector_type(4))) short fa_s16x4_t;
 typedef __attribute__((address_space(3))) fa_s16x4_t* fa_lds_v4_t;
 
-template <int D, int NW>
+// MAXT > 0: the WHOLE key sequence (<= MAXT tiles of 64 keys) is staged in LDS at once -- every K / V chunk is requested up front
+// (one exposed memory latency per workgroup instead of one per tile), ONE barrier, and from then on the waves run their tiles with
+// no workgroup synchronisation at all, so the MFMA and the softmax VALU phases of different waves interleave freely.  MAXT = 0: the
+// tile-by-tile form (one 16 / 32 KiB tile in LDS, two barriers per tile) for sequences that do not fit.
+template <int D, int NW, int MAXT>
 __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
     constexpr int FA_QB = NW * 32, NT = NW * 64;
     constexpr int KST = D / 32;         // MFMA k-steps over the head dim (Q K^T)
     constexpr int DT = D / 16;          // 16-wide output d tiles (P V)
     constexpr int CH = D / 8;           // 16-byte chunks per K/V row
     constexpr int NLD = (FA_KV * CH + NT - 1) / NT;  // staging loads per thread per operand
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[2 * FA_KV * D * 2];   // [K tile | V tile]
+    constexpr int TILE_BYTES = 2 * FA_KV * D * 2;                                           // [K tile | V tile]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];                 // TILE_BYTES x max(MAXT, 1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kg * a.v_rs + ch * 8);
         }
     };
-    auto store_tile = [&]() {
-        unsigned char* ks = lds_all;
+    auto store_tile = [&](int slot) {
+        unsigned char* ks = lds_all + slot * TILE_BYTES;
         unsigned char* vts = ks + FA_KV * D * 2;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -127,10 +132,10 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
     };
 
     // ---- one key tile of 64 keys against the wave's 32 query rows
-    auto tile_body = [&](int kv0) {
+    auto tile_body = [&](int kv0, int slot) {
         constexpr int NTK = 4, NS = 2;
-        const unsigned char* ks = lds_all;
-        const auto fa_lds_base = (__attribute__((address_space(3))) unsigned char*)lds_all + FA_KV * D * 2;   // the V tile, as an LDS pointer
+        const unsigned char* ks = lds_all + slot * TILE_BYTES;
+        const auto fa_lds_base = (__attribute__((address_space(3))) unsigned char*)lds_all + slot * TILE_BYTES + FA_KV * D * 2;   // the V tile, as an LDS pointer
         // ---- S^T = K Q^T
         f32x4_t sacc[2][NTK];
 #pragma unroll
@@ -229,25 +234,48 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
             }
         }
     };
-    auto run_tile = [&](int tile) {
+    auto run_tile = [&](int tile, int slot) {
         const int kv0 = tile * FA_KV;
         // causal: a wave whose rows all precede this tile has nothing to do here
         const bool skip = !wave_active || (a.causal && kv0 > (qw + 31 < Tq ? qw + 31 : Tq - 1) + coff);
         if (skip) return;
-        tile_body(kv0);
+        tile_body(kv0, slot);
     };
 
     // (Measured and dropped, profiles/r03_*: both tiles double-buffered in LDS so that a key tile costs one barrier instead of two --
     // 58.3 -> 62.3 us for the ViT at B = 64, 23.0 -> 25.4 us for the resampler: the second buffer's LDS costs more co-residency
     // than the barrier it removes.)
-    if (ntiles > 0) load_tile(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        __syncthreads();  // previous tile fully consumed
-        store_tile();
+    if constexpr (MAXT > 0) {
+        // whole-sequence form (the launcher guarantees ntiles <= MAXT): request everything, park it, one barrier, compute
+        u32x4_t ak[MAXT][NLD], av[MAXT][NLD];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < ntiles) {
+                load_tile(t);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) { ak[t][i] = rk[i]; av[t][i] = rv[i]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < ntiles) {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) { rk[i] = ak[t][i]; rv[i] = av[t][i]; }
+                store_tile(t);
+            }
+        }
         __syncthreads();
-        load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
-                                                         // prefetch registers out of scratch
-        run_tile(tile);
+        for (int tile = 0; tile < ntiles; ++tile) run_tile(tile, tile);
+    } else {
+        if (ntiles > 0) load_tile(0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            __syncthreads();  // previous tile fully consumed
+            store_tile(0);
+            __syncthreads();
+            load_tile(tile + 1 < ntiles ? tile + 1 : tile);  // unconditional (last one is a harmless re-load): keeps the
+                                                             // prefetch registers out of scratch
+            run_tile(tile, 0);
+        }
     }
 
     if (!wave_active) return;
@@ -328,10 +356,33 @@ int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     if (!a->causal && a->D == 64) nw = a->Tq <= 64 ? 2 : ((a->Tq > 128 && (int64_t)a->B * a->H >= 256) ? 9 : 4);
     if (nw_env == 4) nw = 4;
     dim3 grid((a->Tq + nw * 32 - 1) / (nw * 32), a->H, a->B);
-    if (a->D == 128) attn_mfma_kernel<128, 4><<<grid, 256, 0, s>>>(*a);
-    else if (nw == 9) attn_mfma_kernel<64, 9><<<grid, 576, 0, s>>>(*a);
-    else if (nw == 2) attn_mfma_kernel<64, 2><<<grid, 128, 0, s>>>(*a);
-    else attn_mfma_kernel<64, 4><<<grid, 256, 0, s>>>(*a);
+    // key tiles the tile loop will walk (the kernel peels 1 - 4 remainder keys of an unmasked bidirectional sequence)
+    int kv = a->Tk;
+    if (!a->causal && !a->key_mask && a->Tk > FA_KV && a->Tk % FA_KV >= 1 && a->Tk % FA_KV <= 4) kv -= a->Tk % FA_KV;
+    const int ntiles = (kv + FA_KV - 1) / FA_KV;
+    static const int whole_env = getenv("VCLA_ATTN_MFMA_WHOLE") ? atoi(getenv("VCLA_ATTN_MFMA_WHOLE")) : 1;   // A/B runs: 0 = always tile by tile
+#define FA_GO(D_, NW_, MAXT_)                                                                                        \
+    {                                                                                                                \
+        auto kern = attn_mfma_kernel<D_, NW_, MAXT_>;                                                                \
+        const size_t lds = (size_t)(2 * FA_KV * D_ * 2) * ((MAXT_) > 0 ? (MAXT_) : 1);                               \
+        static bool attr_set[VCLA_MAX_DEVICES] = {};                                                                 \
+        if (lds > 64 * 1024) { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; } \
+        kern<<<grid, (NW_) * 64, lds, s>>>(*a);                                                                      \
+    }
+    if (a->D == 128) {
+        // causal prefill: a 128-token prompt is 2 tiles = 64 KiB (two 4-wave workgroups per CU)
+        if (whole_env && ntiles <= 2 && (int64_t)a->B * a->H * grid.x >= 512) FA_GO(128, 4, 2)
+        else FA_GO(128, 4, 0)
+    } else if (nw == 9) {
+        if (whole_env && ntiles <= 4) FA_GO(64, 9, 4)      // ViT-L/14 at 224 px: 257 keys = 4 tiles + 1 peeled key, 64 KiB
+        else FA_GO(64, 9, 0)
+    } else if (nw == 2) {
+        if (whole_env && ntiles <= 5 && (int64_t)a->B * a->H >= 512) FA_GO(64, 2, 5)   // resampler: 321 keys = 5 tiles + 1, 80 KiB
+        else FA_GO(64, 2, 0)
+    } else {
+        FA_GO(64, 4, 0)
+    }
+#undef FA_GO
     VCLA_CHECK_LAUNCH("attn_mfma_kernel");
     return VCLA_OK;
 }

@@ -140,6 +140,14 @@ struct vcla_ctx {
         float* q8s_ws = nullptr;
         int ssq_parts = 0;             // layout of the deferred-RMSNorm row statistics the last producer wrote (see gemm_ds)
     } run;
+    // cached graphs of the vision stack and of the prefill (fixed launch sequences per shape: ~250 / ~290 launches that are host-bound
+    // at B = 1).  Keyed on every pointer and shape the captured launches bake in; see run_macro.
+    struct MacroGraph {
+        hipGraphExec_t exec = nullptr;
+        const void* key[8] = {};    // of the captured graph
+        const void* seen[8] = {};   // of the previous eager call
+        int has_seen = 0;
+    } vision_graph, prefill_graph;
     // cached decode graph
     hipGraphExec_t graph_exec = nullptr;        // one decode step
     hipGraphExec_t graph_exec_multi = nullptr;  // VCLA_GRAPH_STEPS decode steps (same key), built on the first loop long enough to use it
@@ -192,6 +200,8 @@ extern "C" void vcla_ctx_destroy(vcla_ctx* ctx) {
     if (!ctx) return;
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph_exec_multi) (void)hipGraphExecDestroy(ctx->graph_exec_multi);
+    if (ctx->vision_graph.exec) (void)hipGraphExecDestroy(ctx->vision_graph.exec);
+    if (ctx->prefill_graph.exec) (void)hipGraphExecDestroy(ctx->prefill_graph.exec);
     delete ctx;
 }
 
@@ -487,7 +497,46 @@ static int tap_copy(void* tap, size_t index, const void* src, size_t bytes, hipS
     return VCLA_OK;
 }
 
+// ------------------------------------------------------------------ macro graphs (vision stack, prefill)
+// run(stream) issues the launch sequence.  Replay when `key` matches the captured graph; capture when it matches the previous eager
+// call; else run eagerly and remember the key.  Capture is illegal on the legacy default stream (s == 0): eager there.
+template <typename F>
+static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipStream_t s, F&& run) {
+    static const int genv = getenv("VCLA_MACRO_GRAPH") ? atoi(getenv("VCLA_MACRO_GRAPH")) : 1;
+    if (!genv || s == nullptr) return run(s);
+    if (g.exec && memcmp(g.key, key, sizeof(g.key)) == 0) {
+        VCLA_CHECK_HIP(hipGraphLaunch(g.exec, s));
+        return VCLA_OK;
+    }
+    // not the captured key: this call runs eagerly (which also leaves every per-device function attribute set); the graph is
+    // (re)captured behind it -- recorded, not executed -- when the key is the very first one or repeats the previous call's, so a
+    // caller whose buffers move on every call never pays for captures it cannot reuse
+    const bool repeat = g.has_seen && memcmp(g.seen, key, sizeof(g.seen)) == 0;
+    const bool first = !g.has_seen;
+    memcpy(g.seen, key, sizeof(g.seen));
+    g.has_seen = 1;
+    const int rc_eager = run(s);
+    if (rc_eager || !(repeat || first)) return rc_eager;
+    hipGraph_t graph = nullptr;
+    VCLA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run(s);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    g.exec = exec;
+    memcpy(g.key, key, sizeof(g.key));
+    return VCLA_OK;
+}
+
 // ------------------------------------------------------------------ vision: ViT + post-LN + resampler + projection
+static int vision_forward_impl(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws, void* vit_tap, void* res_tap,
+                               hipStream_t s);
+
 extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws,
                                    size_t ws_bytes, void* vit_tap, void* res_tap, void* stream) {
     VCLA_REQUIRE(ctx && ctx->finalized, VCLA_ERR_BAD_ARG, "vision_forward: context not finalized");
@@ -495,8 +544,15 @@ extern "C" int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void
     VCLA_REQUIRE(B > 0, VCLA_ERR_BAD_SHAPE, "vision_forward: B=%d", B);
     VCLA_REQUIRE(ws_bytes >= vcla_vision_workspace_bytes(ctx, B), VCLA_ERR_WORKSPACE, "vision_forward: workspace %zu < %zu bytes",
                  ws_bytes, vcla_vision_workspace_bytes(ctx, B));
-    const vcla_model_cfg& c = ctx->c;
     hipStream_t s = (hipStream_t)stream;
+    if (vit_tap || res_tap) return vision_forward_impl(ctx, pixel_values, image_embeds, B, ws, vit_tap, res_tap, s);   // parity runs: eager
+    const void* const key[8] = {pixel_values, image_embeds, ws, (const void*)(intptr_t)B, (const void*)(intptr_t)ctx->c.v_image, nullptr, nullptr, nullptr};
+    return run_macro(ctx->vision_graph, key, s, [&](hipStream_t st) { return vision_forward_impl(ctx, pixel_values, image_embeds, B, ws, nullptr, nullptr, st); });
+}
+
+static int vision_forward_impl(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws, void* vit_tap, void* res_tap,
+                               hipStream_t s) {
+    const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const size_t e = esz(ctx);
     const int g = c.v_image / c.v_patch, np = g * g, N = np + 1, D = c.v_hidden, H = c.v_heads, d = D / H;
@@ -665,6 +721,9 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     return VCLA_OK;
 }
 
+static int llama_prefill_impl(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache, int ctx_max,
+                              const int32_t* key_mask, float* logits, int all_logits, void* ws, void* layer_tap, hipStream_t s);
+
 extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache,
                                   int ctx_max, const int32_t* key_mask, float* logits, int all_logits, void* ws,
                                   size_t ws_bytes, void* layer_tap, void* stream) {
@@ -676,6 +735,17 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
     VCLA_REQUIRE(ws_bytes >= vcla_llama_workspace_bytes(ctx, B, T), VCLA_ERR_WORKSPACE, "llama_prefill: workspace %zu < %zu bytes",
                  ws_bytes, vcla_llama_workspace_bytes(ctx, B, T));
     hipStream_t s = (hipStream_t)stream;
+    if (layer_tap) return llama_prefill_impl(ctx, inputs_embeds, B, T, pos0, kv_cache, ctx_max, key_mask, logits, all_logits, ws, layer_tap, s);
+    const void* const key[8] = {inputs_embeds, kv_cache, key_mask, logits, ws, (const void*)(((intptr_t)B << 32) | (uint32_t)T),
+                                (const void*)(((intptr_t)pos0 << 32) | (uint32_t)ctx_max), (const void*)(intptr_t)(all_logits + 2 * c.t_fp8_mfma)};
+    return run_macro(ctx->prefill_graph, key, s, [&](hipStream_t st) {
+        return llama_prefill_impl(ctx, inputs_embeds, B, T, pos0, kv_cache, ctx_max, key_mask, logits, all_logits, ws, nullptr, st);
+    });
+}
+
+static int llama_prefill_impl(vcla_ctx* ctx, const void* inputs_embeds, int B, int T, int pos0, void* kv_cache, int ctx_max,
+                              const int32_t* key_mask, float* logits, int all_logits, void* ws, void* layer_tap, hipStream_t s) {
+    const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const size_t e = esz(ctx);
     const int D = c.t_hidden, M = B * T;

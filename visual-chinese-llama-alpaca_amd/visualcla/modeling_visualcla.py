@@ -182,9 +182,12 @@ class VisualCLAModel:
         model = cls.from_state_dict(config, sd, default_device, torch_dtype)
         model.generation_config = cls._load_generation_config(os.path.join(path, "text_encoder"), config.text_config)
         if load_in_8bit:
-            # the reference quantises the LLaMA only (bitsandbytes int8, modeling_visualcla.py:151-156); the MI355X analogue is
-            # the OCP fp8 (e4m3fn) weight path on the fp8 MFMA pipe
-            model.enable_fp8_decode()
+            # the reference quantises the LLaMA WEIGHTS only (bitsandbytes int8, modeling_visualcla.py:151-156); the MI355X analogue
+            # is the OCP fp8 (e4m3fn) weight copies with bf16 activations (W8A16: decode kernels dequantise in registers, the
+            # prefill keeps the bf16 MFMA tiles).  The fp8 x fp8 prefill (W8A8, fp8 MFMA pipe) stays an explicit opt-in
+            # (enable_fp8_decode(prefill=True)): e4m3 activations add ~2.6 % rms per GEMM whatever the scale granularity
+            # (tools/fp8_scale_study.py, profiles/r03_fp8_scale_study.txt).
+            model.enable_fp8_decode(True, prefill=False)
         return model
 
     @staticmethod
@@ -250,7 +253,7 @@ class VisualCLAModel:
         model = cls.from_state_dict(visualcla_config, sd, default_device, torch_dtype)
         model.generation_config = cls._load_generation_config(text_model_name_or_path, visualcla_config.text_config)
         if load_in_8bit:
-            model.enable_fp8_decode()      # MI355X analogue of bitsandbytes int8 on the LLaMA (modeling_visualcla.py:246-251)
+            model.enable_fp8_decode(True, prefill=False)   # fp8 weights, bf16 activations (see from_merged_pretrained)
         return model
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -402,7 +405,16 @@ class VisualCLAModel:
         return tk.img_start_token_id, tk.img_end_token_id, tk.img_token_id
 
     # ------------------------------------------------------------------ stages
-    def embed_images(self, pixel_values: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def _typed_buf(self, key: str, shape, dtype: torch.dtype) -> torch.Tensor:
+        """a persistent device buffer viewed as `shape` / `dtype`: the same address on every call with the same shape, which is what
+        lets the engine replay its captured vision / prefill graphs (engine.hip run_macro) instead of re-issuing ~500 launches"""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return self._buf(key, nbytes)[:nbytes].view(dtype).view(*shape)
+
+    def embed_images(self, pixel_values: torch.Tensor, taps: Optional[dict] = None, _persistent: bool = False) -> torch.Tensor:
         """[B, 3, H, W] -> [B, num_query_tokens, text_hidden]: ViT + post-LN + Resampler + projection
         (the vision half; also what tgwebui's embed_images() computes, .../visualcla/visualcla.py:116-129)."""
         lib = _lib.load()
@@ -413,7 +425,8 @@ class VisualCLAModel:
                              f"({v['image_size']}*{v['image_size']}).")
         B = pixel_values.shape[0]
         px = pixel_values.to(device=self._device, dtype=self._dtype).contiguous()
-        out = torch.empty(B, r["num_query_tokens"], t["hidden_size"], dtype=self._dtype, device=self._device)
+        shape = (B, r["num_query_tokens"], t["hidden_size"])
+        out = self._typed_buf("gen_img", shape, self._dtype) if _persistent else torch.empty(*shape, dtype=self._dtype, device=self._device)
         nbytes = lib.vcla_vision_workspace_bytes(self._ctx, B)
         ws = self._buf("vision", nbytes)
         vit_tap = res_tap = None
@@ -449,7 +462,7 @@ class VisualCLAModel:
             raise ValueError(f"Num of patch ({Q}) is not equal to the length of pre-filled image patch tokens.")
         return torch.where(has, p0, torch.full_like(p0, -1)).to(torch.int32)
 
-    def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], for_generate: bool):
+    def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], for_generate: bool, _persistent: bool = False):
         """-> (inputs_embeds [B, T', D], attention-mask extension length).  Handles both placements."""
         lib = _lib.load()
         t = self.config.text_config
@@ -476,17 +489,19 @@ class VisualCLAModel:
                 img_pos = self._find_image_slots(ids, Q, need_img_token=not for_generate)
         ids = ids.contiguous()
         Tn = ids.shape[1]
-        out = torch.empty(B, Tn, D, dtype=self._dtype, device=self._device)
+        out = self._typed_buf("gen_embeds", (B, Tn, D), self._dtype) if _persistent else torch.empty(B, Tn, D, dtype=self._dtype, device=self._device)
         with torch.cuda.device(self._device):
             _lib.check(lib.vcla_embed_splice(ids.data_ptr(), self._packed["llama.embed"].data_ptr(),
                                              _lib.ptr(image_embeds), _lib.ptr(img_pos), out.data_ptr(), B, Tn, Q, D, V,
                                              _lib.dtype_code(self._dtype), _lib.stream_ptr()))
         return out, extra
 
-    def _new_cache(self, B: int, ctx_max: int) -> VclaCache:
+    def _new_cache(self, B: int, ctx_max: int, _persistent: bool = False) -> VclaCache:
         t = self.config.text_config
         H, d = t["num_attention_heads"], t["hidden_size"] // t["num_attention_heads"]
-        kv = torch.empty(t["num_hidden_layers"], 2, B, H, ctx_max, d, dtype=self._dtype, device=self._device)
+        shape = (t["num_hidden_layers"], 2, B, H, ctx_max, d)
+        # generate()'s own cache lives in a persistent buffer (never handed to the caller); forward(use_cache=True) returns a fresh one
+        kv = self._typed_buf("gen_kv", shape, self._dtype) if _persistent else torch.empty(*shape, dtype=self._dtype, device=self._device)
         return VclaCache(kv, 0, ctx_max)
 
     def _key_mask(self, attention_mask: Optional[torch.Tensor], B: int, T: int, ctx_max: int, extra: int):
@@ -514,7 +529,7 @@ class VisualCLAModel:
         km[:, :T] = am.to(torch.int32)
         return km
 
-    def _prefill(self, embeds: torch.Tensor, cache: VclaCache, key_mask, all_logits: bool, taps: Optional[dict] = None):
+    def _prefill(self, embeds: torch.Tensor, cache: VclaCache, key_mask, all_logits: bool, taps: Optional[dict] = None, _persistent: bool = False):
         lib = _lib.load()
         t = self.config.text_config
         B, T, D = embeds.shape
@@ -522,7 +537,8 @@ class VisualCLAModel:
         pos0 = cache.length
         if pos0 + T > cache.ctx_max:
             raise ValueError(f"sequence length {pos0 + T} exceeds the KV cache capacity {cache.ctx_max}")
-        logits = torch.empty((B, T, V) if all_logits else (B, V), dtype=torch.float32, device=self._device)
+        lshape = (B, T, V) if all_logits else (B, V)
+        logits = self._typed_buf("gen_logits", lshape, torch.float32) if _persistent else torch.empty(lshape, dtype=torch.float32, device=self._device)
         nbytes = lib.vcla_llama_workspace_bytes(self._ctx, B, T)
         ws = self._buf("llama", nbytes)
         tap = None
@@ -663,8 +679,31 @@ class VisualCLAModel:
         t = self.config.text_config
         input_ids = input_ids.to(self._device)
         B = input_ids.shape[0]
-        img = self.embed_images(pixel_values) if pixel_values is not None else None
-        embeds, extra = self._embed(input_ids, img, for_generate=True)
+        if use_graph is None:
+            use_graph = os.environ.get("VCLA_DECODE_GRAPH", "1") != "0"
+        # hipGraph capture (decode loop; vision stack and prefill inside the engine) is illegal on the legacy default stream: the
+        # whole request hops onto a side stream, and its stage buffers are persistent so that every call presents the same addresses
+        cur_stream = torch.cuda.current_stream(self._device)
+        side = None
+        if use_graph and cur_stream.cuda_stream == 0:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=self._device)
+            side = self._side_stream
+            side.wait_stream(cur_stream)
+        with torch.cuda.device(self._device), torch.cuda.stream(side if side is not None else cur_stream):
+            toks = self._generate_on_stream(gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph,
+                                            device_sampling)
+        if side is not None:
+            cur_stream.wait_stream(side)
+        return toks
+
+    def _generate_on_stream(self, gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph, device_sampling):
+        lib = _lib.load()
+        t = self.config.text_config
+        B = input_ids.shape[0]
+        persistent = bool(use_graph)
+        img = self.embed_images(pixel_values, _persistent=persistent) if pixel_values is not None else None
+        embeds, extra = self._embed(input_ids, img, for_generate=True, _persistent=persistent)
         T = embeds.shape[1]
         max_pos = t["max_position_embeddings"]
         if gc.max_new_tokens is not None:
@@ -675,9 +714,9 @@ class VisualCLAModel:
         if n_new <= 0:
             raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
         ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
-        cache = self._new_cache(B, ctx_max)
+        cache = self._new_cache(B, ctx_max, _persistent=persistent)
         key_mask = self._key_mask(attention_mask, B, T, ctx_max, extra)
-        logits = self._prefill(embeds, cache, key_mask, all_logits=False)
+        logits = self._prefill(embeds, cache, key_mask, all_logits=False, _persistent=persistent)
 
         eos = self._eos_list(gc)
         pad_id = gc.pad_token_id if gc.pad_token_id is not None else (eos[0] if eos else 0)
@@ -685,8 +724,6 @@ class VisualCLAModel:
         criteria = list(stopping_criteria) if stopping_criteria else []
         ws = self._buf("llama", lib.vcla_llama_workspace_bytes(self._ctx, B, 1))
         stream = _lib.stream_ptr()
-        if use_graph is None:
-            use_graph = os.environ.get("VCLA_DECODE_GRAPH", "1") != "0"
 
         plain_greedy = not procs and not gc.do_sample
         samp_kw = None
@@ -698,7 +735,7 @@ class VisualCLAModel:
         fast = not criteria and (plain_greedy or samp_kw is not None)
         if fast:
             # ---- device-resident loop: argmax, or the on-device sampler, feeds the next step
-            out = torch.empty(n_new, B, dtype=torch.int64, device=self._device)
+            out = self._typed_buf("gen_out", (n_new, B), torch.int64) if persistent else torch.empty(n_new, B, dtype=torch.int64, device=self._device)
             samp = None
             if samp_kw is not None:
                 self._uniforms = torch.rand(n_new, B, device=self._device) if gc.do_sample else None
@@ -712,30 +749,19 @@ class VisualCLAModel:
             done_at = n_new
             step, chunk = 1, (n_new if not eos else 32)
             self._pos_dev.zero_()
-            # hipGraph capture is illegal on the legacy default stream: hop onto a side stream for the loop
-            cur_stream = torch.cuda.current_stream(self._device)
-            eos_t = torch.tensor(eos, device=self._device) if eos else None   # created BEFORE the side stream forks off
-            side = None
-            if use_graph and cur_stream.cuda_stream == 0:
-                if getattr(self, "_side_stream", None) is None:
-                    self._side_stream = torch.cuda.Stream(device=self._device)
-                side = self._side_stream
-                side.wait_stream(cur_stream)
-            with torch.cuda.device(self._device), torch.cuda.stream(side if side is not None else cur_stream):
-                # position of decode step i's input token = T + *pos_dev; the counter runs 0,1,2,... across chunks so
-                # the captured graph (keyed on buffers + pos0) is reused for the whole generate() call
-                while step < n_new:
-                    k = min(chunk, n_new - step)
-                    _lib.check(lib.vcla_llama_decode_loop_sampled(
-                        self._ctx, out[step - 1].data_ptr(), B, T, self._pos_dev.data_ptr(), k, cache.kv.data_ptr(), ctx_max,
-                        _lib.ptr(key_mask), out[1:].data_ptr(), ws.data_ptr(), ws.numel(), int(use_graph),
-                        C.byref(samp) if samp is not None else None, 1, _lib.stream_ptr()))
-                    step += k
-                    if eos_t is not None and bool(torch.isin(out[:step], eos_t).any(dim=0).all()):
-                        done_at = step
-                        break
-            if side is not None:
-                cur_stream.wait_stream(side)
+            eos_t = torch.tensor(eos, device=self._device) if eos else None
+            # position of decode step i's input token = T + *pos_dev; the counter runs 0,1,2,... across chunks so
+            # the captured graph (keyed on buffers + pos0) is reused for the whole generate() call
+            while step < n_new:
+                k = min(chunk, n_new - step)
+                _lib.check(lib.vcla_llama_decode_loop_sampled(
+                    self._ctx, out[step - 1].data_ptr(), B, T, self._pos_dev.data_ptr(), k, cache.kv.data_ptr(), ctx_max,
+                    _lib.ptr(key_mask), out[1:].data_ptr(), ws.data_ptr(), ws.numel(), int(use_graph),
+                    C.byref(samp) if samp is not None else None, 1, _lib.stream_ptr()))
+                step += k
+                if eos_t is not None and bool(torch.isin(out[:step], eos_t).any(dim=0).all()):
+                    done_at = step
+                    break
             toks = out[:min(step, done_at)].t().contiguous()
             if eos:
                 is_eos = torch.isin(toks, torch.tensor(eos, device=self._device))
