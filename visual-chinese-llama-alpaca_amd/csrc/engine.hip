@@ -504,10 +504,13 @@ template <typename F>
 static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipStream_t s, F&& run) {
     static const int genv = getenv("VCLA_MACRO_GRAPH") ? atoi(getenv("VCLA_MACRO_GRAPH")) : 1;
     if (!genv || s == nullptr) return run(s);
+    static const int dbg = getenv("VCLA_MACRO_GRAPH_DEBUG") ? atoi(getenv("VCLA_MACRO_GRAPH_DEBUG")) : 0;
     if (g.exec && memcmp(g.key, key, sizeof(g.key)) == 0) {
         VCLA_CHECK_HIP(hipGraphLaunch(g.exec, s));
+        if (dbg) fprintf(stderr, "[vcla] macro graph %p: replay\n", (void*)&g);
         return VCLA_OK;
     }
+    if (dbg) fprintf(stderr, "[vcla] macro graph %p: eager call (%s)\n", (void*)&g, g.exec ? "key differs from the captured one" : "nothing captured yet");
     // not the captured key: this call runs eagerly (which also leaves every per-device function attribute set); the graph is
     // (re)captured behind it -- recorded, not executed -- when the key is the very first one or repeats the previous call's, so a
     // caller whose buffers move on every call never pays for captures it cannot reuse

@@ -1516,8 +1516,11 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                     tail.C = (char*)a->C + (size_t)head.M * a->ldc * cs;
                     if (a->residual) tail.residual = (const char*)a->residual + (size_t)head.M * a->ldr * es;
                     head.force_kernel = 4;
-                    static const int tail_env = getenv("VCLA_TAIL_KERNEL") ? atoi(getenv("VCLA_TAIL_KERNEL")) : 0;   // A/B: 7 = skinny (one launch)
-                    if (tail_env == 7 && rem <= 128 && !a->post_norm_gamma) tail.force_kernel = 7;
+                    // the tail: one launch of the skinny kernel (intra-workgroup split-K, epilogue in the kernel) for short K, the split-K
+                    // panel kernel + its reduce launch for long K.  Measured at 64 rows (tools/bench_kernels.py vittail): K = 1024:
+                    // 9.7 - 10.8 us vs 11.6 - 13.6 us; K = 4096: 28.1 vs 15.6 us.  VCLA_TAIL_KERNEL = 7 / 8 forces one form.
+                    static const int tail_env = getenv("VCLA_TAIL_KERNEL") ? atoi(getenv("VCLA_TAIL_KERNEL")) : 0;
+                    if (!a->post_norm_gamma && (tail_env == 7 || (tail_env == 0 && a->K <= 2048))) tail.force_kernel = 7;
                     head.post_norm_gamma = tail.post_norm_gamma = nullptr;   // the wrapper normalises all of C afterwards
                     int rc = gemm_impl(&head, dtype, stream);
                     return rc ? rc : gemm_impl(&tail, dtype, stream);
