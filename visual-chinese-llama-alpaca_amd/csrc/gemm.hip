@@ -171,9 +171,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+#ifdef VCLA_G2_TIMELINE   // debug build only (make -C csrc timeline -> tools/libvcla_timeline.so): per-workgroup phase stamps, 100 MHz wall clock
+__device__ unsigned long long* g2_timeline = nullptr;      // [workgroup][8]: entry, first slab landed, K loop done, epilogue issued, stores drained
+extern "C" int vcla_debug_set_timeline(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g2_timeline), &p, sizeof(p)); }
+#define G2_STAMP(i_) do { if (g2_timeline && threadIdx.x == 0) g2_timeline[(size_t)blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
+// K-loop ablations are COMPILE-time (-DVCLA_G2_ABLATE=1/2/3; results are garbage): 1 = no fragment reads (MFMA + DMA only), 2 = no MFMAs
+// (LDS reads + DMA only), 3 = no DMA after the first slab (MFMA + LDS reads only).  (A run-time switch wrecked the loop's code.)
+#else
+#define G2_STAMP(i_) do { } while (0)
+#endif
+
 template <int EPI, typename OutT, bool SGB>
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB]
+    G2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = tiles_m * tiles_n;
@@ -233,6 +244,10 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = (kt + p0) & 1;
             __syncthreads();  // (compiler adds vmcnt(0)): slab kt has landed for every wave, and buffer cur^1 is no longer read
+            if (kt == 0) G2_STAMP(1);
+#if defined(VCLA_G2_ABLATE) && VCLA_G2_ABLATE == 3
+            if (kt >= 1) { /* no more DMA */ } else
+#endif
             if (kt + 1 < nk) {
                 issue(kt + 1, cur ^ 1);
             } else if (has_next) {   // last K step: the staging pointers of this tile are dead -> re-aim them at the next tile
@@ -246,17 +261,31 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t wf[4];
+                bf16x8_t af[8];
+#if defined(VCLA_G2_ABLATE) && VCLA_G2_ABLATE == 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wf[j] = __builtin_bit_cast(bf16x8_t, acc[j][0]); asm volatile("" : "+v"(wf[j])); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { af[i] = __builtin_bit_cast(bf16x8_t, acc[i][1]); asm volatile("" : "+v"(af[i])); }
+#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fch));
-                bf16x8_t af[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * 128 + i * 16 + frow, kk * 4 + fch));
+#endif
+#if defined(VCLA_G2_ABLATE) && VCLA_G2_ABLATE == 2
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(wf[j]));      // keep the reads live (guide rule 17)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(af[i]));
+#else
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+#endif
                 if (SGB) {
                     // issue order: 6 fragment reads (4 W + 2 A), then 4 MFMAs per further A read, so every ds_read runs
                     // two fragments ahead of the MFMAs that consume it
@@ -270,7 +299,13 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
                 }
             }
         }
+        G2_STAMP(2);
         gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        G2_STAMP(3);
+#ifdef VCLA_G2_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0);
+        G2_STAMP(4);
+#endif
         if (!has_next) break;
         p0 = (nk + p0) & 1;     // slab 0 of the next tile went into the buffer the last K step did not read
         tile = next; m0 = nm0; n0 = nn0;
