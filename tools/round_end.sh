@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end measurement set (one gpurun call): full GPU test suite, smoke, the bench lines of every configuration, rocprofv3
-# kernel stats of the two main bench commands, kernel microbenchmarks.  Artifacts: gpurun_out/<tag>_*; copy the ones to be
-# judged into profiles/.   usage: bash tools/round_end.sh r02
+# kernel stats of the two main bench commands (grouped by (kernel, grid)), PMC passes (separate, counters only), kernel
+# microbenchmarks.  Artifacts: gpurun_out/<tag>_*; copy the ones to be judged into profiles/.   usage: bash tools/round_end.sh r03
 tag=${1:-rXX}
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
@@ -9,20 +9,36 @@ mkdir -p gpurun_out
 rm -f gpurun_out/parity_report.txt
 echo "== tests"; timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -5 | tee gpurun_out/${tag}_gpu_tests.txt
 cp gpurun_out/parity_report.txt gpurun_out/${tag}_parity_report.txt 2>/dev/null
-echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2
-echo "== bench (default)"; timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -1 > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json
-echo "== bench B=64"; timeout 900 python bench.py --batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_b64.json; cut -c1-300 gpurun_out/${tag}_bench_b64.json
+echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee -a gpurun_out/${tag}_gpu_tests.txt
+echo "== bench (default)"; timeout 900 python bench.py --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json
+echo "== bench B=64"; timeout 900 python bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_b64.json; cut -c1-300 gpurun_out/${tag}_bench_b64.json
 echo "== bench fp8"; timeout 600 python bench.py --fp8 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_fp8.json; cut -c1-200 gpurun_out/${tag}_bench_fp8.json
 echo "== bench fp8 B=64"; timeout 900 python bench.py --fp8 --batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_fp8_b64.json; cut -c1-200 gpurun_out/${tag}_bench_fp8_b64.json
+echo "== bench fp8 336px B=32 (per-GPU share of configs[4])"; timeout 900 python bench.py --fp8 --image-size 336 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_336px_fp8_b32.json; cut -c1-200 gpurun_out/${tag}_bench_336px_fp8_b32.json
 echo "== bench sampled"; timeout 600 python bench.py --sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_sample.json; cut -c1-200 gpurun_out/${tag}_bench_sample.json
+echo "== bench strong scaling mode, 1 GPU (global batch 256 = 4 x 64 would not fit one step's buffers of the default; 64 here)"; timeout 900 python bench.py --global-batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_strong_gb64.json; cut -c1-200 gpurun_out/${tag}_bench_strong_gb64.json
 for cfg in "b1:--steps 2 --warmup 1 --steps-b64 0 --no-cpu-baseline" "b64:--batch 64 --steps 1 --warmup 1 --no-cpu-baseline"; do
   nm=${cfg%%:*}; args=${cfg#*:}
   echo "== rocprofv3 --kernel-trace --stats: bench.py $args"
   rm -rf gpurun_out/prof_$nm
   (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$nm -o bench -- python $R/bench.py $args 2>&1 | tail -1 | cut -c1-200)
   f=$(find gpurun_out/prof_$nm -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_bench_${nm}_kernel_stats.csv && head -12 $f | cut -c1-160
-  f=$(find gpurun_out/prof_$nm -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/prof_by_grid.py $f 16 | tee gpurun_out/${tag}_bench_${nm}_by_grid.txt
+  f=$(find gpurun_out/prof_$nm -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/prof_by_grid.py $f 24 | tee gpurun_out/${tag}_bench_${nm}_by_grid.txt
   rm -rf gpurun_out/prof_$nm
 done
+echo "== PMC passes (counters only, one counter per run)"
+pmc() { # counter workload-script kernel-filter outfile [env]
+  rm -rf gpurun_out/pmcx
+  (cd /tmp && export TMPDIR=/tmp && env $5 timeout 600 rocprofv3 --pmc $1 --output-format csv -d $R/gpurun_out/pmcx -o pmc -- python $R/$2 2>&1 | tail -1 | cut -c1-80)
+  f=$(find gpurun_out/pmcx -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python tools/pmc_summary.py "$f" $1 $3 | tee -a gpurun_out/$4
+  rm -rf gpurun_out/pmcx
+}
+rm -f gpurun_out/${tag}_pmc_*.txt
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_gemv.py gemv1p_kernel ${tag}_pmc_gemv1p_$(echo $c | tr A-Z a-z).txt; done
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_dstream.py gemm_dstream_kernel ${tag}_pmc_dstream_$(echo $c | tr A-Z a-z).txt; done
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_attn_decode.py attn_decode_flash_kernel ${tag}_pmc_attn_decode_b64_$(echo $c | tr A-Z a-z).txt; done
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES; do pmc $c tools/pmc_gemm.py gemm_mfma256_kernel ${tag}_pmc_vit_fc1_mfma.txt VCLA_PMC_SHAPE=vit; done
 echo "== microbench"
-(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit 2>&1 | grep "^vit"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
+(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
+echo "== done"
