@@ -223,6 +223,27 @@ def test_single_token_forward_on_a_cache_matches_the_full_forward(B, dtype):
     assert torch.isfinite(taps["final_norm"].float()).all()
 
 
+def test_prefix_allowed_tokens_fn_constrains_generation():
+    """the reference forwards `prefix_allowed_tokens_fn` to HF generate (modeling_visualcla.py:382-391): every new token must come
+    from the allowed set, and an unconstrained call is unchanged"""
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 2, 24)
+    m = make_hip_model(cfg, W, torch.float32)
+    allowed = [5, 7, 11, 13]
+    kw = dict(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=5, do_sample=False, eos_token_id=None)
+    got = m.generate(prefix_allowed_tokens_fn=lambda batch_id, sent: allowed, **kw).cpu()
+    assert got.shape == (2, 5) and bool(torch.isin(got, torch.tensor(allowed)).all())
+    # oracle: greedy over the allowed ids only
+    want = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=5,
+                                select_fn=lambda lg, gen: torch.tensor(allowed)[lg[:, allowed].argmax(-1)])
+    assert torch.equal(got, want)
+    free = m.generate(**kw).cpu()
+    assert torch.equal(free, O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=5))
+    with pytest.raises(ValueError):
+        m.generate(num_beams=2, **kw)
+
+
 def test_state_dict_roundtrip_and_dtype_switch():
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)

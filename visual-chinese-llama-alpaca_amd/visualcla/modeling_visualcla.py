@@ -669,13 +669,16 @@ class VisualCLAModel:
         callbacks runs entirely on the device (argmax feeds the next step; optional hipGraph replay); so does sampling /
         greedy with HF's standard processors (repetition penalty, no-repeat-ngram, min-new-tokens, temperature, top-k <= 256,
         top-p) through vcla_sample, drawing from torch.rand(n_new, B) of the device generator.  Custom logits processors,
-        stopping criteria (streaming) or top_k = 0 take the host-driven path (HF processors + torch.multinomial)."""
-        lib = _lib.load()
-        if prefix_allowed_tokens_fn is not None:
-            raise ValueError("prefix_allowed_tokens_fn is not supported")
+        stopping criteria (streaming), `prefix_allowed_tokens_fn` or top_k = 0 take the host-driven path (HF processors +
+        torch.multinomial)."""
         gc = self._resolve_generation_config(generation_config, kwargs)
         if (gc.num_beams or 1) != 1 or (gc.num_return_sequences or 1) != 1:
             raise ValueError("only num_beams=1, num_return_sequences=1 is supported")
+        if prefix_allowed_tokens_fn is not None:
+            # the reference forwards it to HF generate (modeling_visualcla.py:382-391), which turns it into this processor; it sees the
+            # NEW tokens only, as every processor does when HF is driven by inputs_embeds.  Host-driven step path.
+            from transformers.generation.logits_process import PrefixConstrainedLogitsProcessor
+            logits_processor = list(logits_processor or []) + [PrefixConstrainedLogitsProcessor(prefix_allowed_tokens_fn, num_beams=1)]
         t = self.config.text_config
         input_ids = input_ids.to(self._device)
         B = input_ids.shape[0]
