@@ -171,6 +171,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(vcla_gemm_args a, int ti
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// LDS-DMA from inline asm (16 B / 4 B per lane to LDS address `lds_dst` + lane * size): invisible to hipcc, which therefore neither
+// counts it nor drains it at the next LDS access or barrier -- the PF form of the kernel below counts vmcnt by hand
+__device__ __forceinline__ void g2_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void g2_dma4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void g2_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 #ifdef VCLA_G2_TIMELINE   // debug build only (make -C csrc timeline -> tools/libvcla_timeline.so): per-workgroup phase stamps, 100 MHz wall clock
 __device__ unsigned long long* g2_timeline = nullptr;      // [workgroup][8]: entry, first slab landed, K loop done, epilogue issued, stores drained
 extern "C" int vcla_debug_set_timeline(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g2_timeline), &p, sizeof(p)); }
@@ -181,11 +195,18 @@ extern "C" int vcla_debug_set_timeline(unsigned long long* p) { return (int)hipM
 #define G2_STAMP(i_) do { } while (0)
 #endif
 
-template <int EPI, typename OutT, bool SGB>
+// PF (VCLA_GEMM_PF=1, round 3): the L2-prefetch form.  The timeline (profiles/r03_gemm256_timeline.txt) shows a K step waiting
+// ~0.6 us of its 1.8 for the next slab: all workgroups of an XCD walk K in step, so every slab is an L2 MISS for its first toucher
+// (~1.9 us to MALL / HBM) and LDS has no room for a second slab in flight.  Here two waves per workgroup TOUCH the lines of the slab
+// after next (one 4-byte LDS-DMA per line into a sink: 64 weight-row lines + 32 activation-row lines per workgroup -- the workgroups
+// of an XCD that share a panel split its lines between them, blockIdx-derived, a pure speed assumption) two K steps before the slab's
+// own DMA is issued, which then finds the lines in L2 or merges with the miss in flight.  All DMA is issued from inline asm and
+// vmcnt is counted by hand (the newest instruction -- the touch -- may stay in flight across the barrier).  One tile per workgroup.
+template <int EPI, typename OutT, bool SGB, bool PF = false>
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB]
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB] (+ 512 B sink, PF)
     G2_STAMP(0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = PF ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = tiles_m * tiles_n;
 
@@ -230,6 +251,81 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
     tile_assign(tile, tiles_m, tiles_n, 4, tm, tn);
     int m0 = tm * G2_BM, n0 = tn * G2_BN;
     set_src(m0, n0);
+    if constexpr (PF) {
+        const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)lds2;
+        auto issue_pf = [&](int kt, int buf) {
+            const unsigned ab = lds_u + buf * 2 * G2_TILE_BYTES, wb = ab + G2_TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned piece = __builtin_amdgcn_readfirstlane((wave * 4 + i) * 1024);
+                g2_dma16(asrc[i] + (int64_t)kt * GM_BK, ab + piece);
+                g2_dma16(wsrc[i] + (int64_t)kt * GM_BK, wb + piece);
+            }
+        };
+        // touch lines: wave 0 = 64 weight rows (quarter tm & 3 of the 256), wave 1 = 32 activation rows (eighth tn & 7); one line per
+        // row and K step
+        const bool pf_wave = wave < 2;
+        int prow = wave == 0 ? n0 + 64 * (tm & 3) + lane : m0 + 32 * (tn & 7) + (lane & 31);
+        if (wave == 0) prow = prow < n_pad ? prow : n_pad - 1; else prow = prow < a.M ? prow : a.M - 1;
+        const bf16_t* pfsrc = wave == 0 ? Wg + (int64_t)prow * a.K : Ag + (int64_t)prow * a.lda;
+        const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 4 * G2_TILE_BYTES + (wave & 1) * 256);
+        auto touch = [&](int kt) {
+            if (pf_wave) g2_dma4(pfsrc + (int64_t)(kt < nk ? kt : nk - 1) * GM_BK, sink);
+        };
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        touch(1);
+        issue_pf(0, 0);
+        touch(2);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (pf_wave) g2_vmcnt<1>(); else g2_vmcnt<0>();      // this wave's pieces of slab kt have landed (the newest touch may not have)
+            __builtin_amdgcn_s_barrier();                        // ... everyone's; and buffer cur^1 is no longer read
+            asm volatile("" ::: "memory");
+            if (kt == 0) G2_STAMP(1);
+            if (kt + 1 < nk) issue_pf(kt + 1, cur ^ 1);
+            touch(kt + 3);
+            const unsigned char* As = lds2 + cur * 2 * G2_TILE_BYTES;
+            const unsigned char* Ws = As + G2_TILE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t wf[4];
+                bf16x8_t af[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fch));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * 128 + i * 16 + frow, kk * 4 + fch));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                if (SGB) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                }
+            }
+            asm volatile("" ::: "memory");                       // the fragment reads stay on this side of the next barrier
+        }
+        g2_vmcnt<0>();                                           // no DMA may land in LDS after the workgroup has given it up
+        G2_STAMP(2);
+        gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        G2_STAMP(3);
+#ifdef VCLA_G2_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0);
+        G2_STAMP(4);
+#endif
+        return;
+    }
     int p0 = 0;                 // LDS buffer that holds K slab 0 of the current tile
     issue(0, p0);
     while (true) {
@@ -1425,7 +1521,16 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     static const int pg = getenv("VCLA_GEMM_PERSIST") ? atoi(getenv("VCLA_GEMM_PERSIST")) : 0;   // measured equal: ViT fc1 180 vs 182 us, LLaMA gate/up 1288 vs 1265 us
+    static const int pf = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 0;
     const int nt = tiles_m * tiles_n;
+    if (pf && a->K >= 3 * GM_BK) {
+        auto kpf = gemm_mfma256_kernel<EPI, OutT, SGB, true>;
+        static bool attr_pf[VCLA_MAX_DEVICES] = {};
+        { const int rc_ = vcla_raise_dyn_lds((const void*)kpf, lds + 512, attr_pf); if (rc_) return rc_; }
+        kpf<<<nt, 512, lds + 512, s>>>(*a, tiles_m, tiles_n, n_pad);
+        VCLA_CHECK_LAUNCH("gemm_mfma256_kernel<PF>");
+        return VCLA_OK;
+    }
     kern<<<(pg && nt > 256) ? 256 : nt, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);   // one workgroup per CU, persistent over tiles
     VCLA_CHECK_LAUNCH("gemm_mfma256_kernel");
     return VCLA_OK;
