@@ -944,3 +944,26 @@ def test_gemm_dstream_splitk(lib, M, N, K, S, fp8):
             ref2 = _gemm_ref(bf16r(gamma * x) * rstd, w2, None, 0, None)      # what the kernels compute, in fp32
             _cmp("gemm_dstream_splitk.consumer", got2, ref2, atol=2e-3, rtol=8e-3)
     assert torch.equal(outs[0][0], outs[1][0])
+    # ---- fused form (ds_tickets): one launch, the last workgroup of a tile group to arrive sums the slices in the same order ->
+    # the SAME bits as the two-launch form; row statistics in the unsplit layout [M][N/16]; the counters are left at zero.
+    # Repeated under a competing launch on a second stream (uneven load is where a broken hand-off shows).
+    tickets = torch.zeros(2048, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    noise = torch.randn(64 << 20, device=DEV)           # 256 MB: an HBM-bound elementwise pass as the competing load
+    for rep in range(6):
+        if rep % 2:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    noise.mul_(1.0001).sin_()
+        xf = res.to(DEV, torch.bfloat16)
+        cff = torch.zeros_like(cf) if cf is not None else None
+        ssqf = torch.zeros(M, N // 16, dtype=torch.float32, device=DEV) if N % 16 == 0 else None
+        lib.gemm(None, wp, N, bias=bias.to(DEV), residual=xf, out=xf, force_kernel=9, a_frag=af, m=M, splitk_ws=ws, ds_splitk=S, ds_tickets=tickets,
+                 c_frag=cff, c_frag_gamma=gamma.to(DEV) if with_frag else None, c_row_ssq=ssqf, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(xf, xd), f"fused split-K differs from the two-launch form (rep {rep})"
+        if cf is not None:
+            assert torch.equal(cff, cf)
+        if ssqf is not None:
+            _cmp("gemm_dstream_splitk.fused.ssq", ssqf.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
+        assert int(tickets.abs().max()) == 0

@@ -24,6 +24,7 @@
 
 #define DS_WAVES 8
 #define DS_ROUND 8   // epilogue units reduced per LDS round (one per wave)
+#define DS_MAX_CHUNKS 16   // fused split-K: arrival counters per tile group (one per chunk of its tile range)
 
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
 __device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
@@ -53,6 +54,9 @@ struct DsCtx {
     int ks;                   // slice index, splitk slices in total
     int splitk;
     float* partial;           // [splitk][M][N] fp32 partial tiles (split-K only)
+    unsigned* tickets;        // split-K, fused form: arrival counters [group][DS_MAX_CHUNKS] (zero between launches); nullptr = reduce launch
+    __amdgpu_buffer_rsrc_t rP; // the partial tiles as a buffer (fused form: write-through stores, L2-bypassing loads)
+    int group, chunk;         // tile group of this workgroup, chunk of the group's tile range being processed
     int M, N;
 };
 
@@ -167,6 +171,9 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
     __builtin_memcpy(&a, (const void*)ap_, sizeof(a));
     if (first && a.a_row_ssq) ds_row_rstd(a, c, rstd_s);
     constexpr int NU = (NT / TPU) * MT;
+    constexpr int NR = (NU + DS_ROUND - 1) / DS_ROUND;
+    f32x4_t mine[NR];            // fused split-K: this wave's own slice sums, one unit per round
+    const bool fused = c.splitk > 1 && c.tickets != nullptr;
 #pragma unroll
     for (int r0 = 0; r0 < NU; r0 += DS_ROUND) {
 #pragma unroll
@@ -192,14 +199,22 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
                 }
             const int jj = u / MT, i = u - jj * MT;
             if (c.splitk > 1) {
-                // split-K: the raw fp32 sums of this K slice go to the workspace; ds_reduce_kernel finishes the tile
+                // split-K: the raw fp32 sums of this K slice go to the workspace; ds_reduce_kernel -- or, fused form, the LAST workgroup
+                // of the group to arrive -- finishes the tile
                 if constexpr (TPU == 1) {
                     const int m = i * 16 + (c.lane & 15), n = (c0 + jj) * 16 + (c.lane >> 4) * 4;
-                    if (m < c.M && n < c.N)      // N % 4 == 0 is checked on the host
+                    const bool in = m < c.M && n < c.N;      // N % 4 == 0 is checked on the host
+                    if (fused) {
+                        mine[r0 / DS_ROUND] = sum[0][0];
+                        // write-through (sc0 sc1): the bytes leave this XCD's L2 for memory, where the other XCDs' L2-bypassing loads find them
+                        const unsigned off = in ? (unsigned)((((int64_t)c.ks * c.M + m) * c.N + n) * 4) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, sum[0][0]), c.rP, off, 0, 17 /* sc0 sc1 */);
+                    } else if (in) {
                         *reinterpret_cast<f32x4_t*>(c.partial + ((int64_t)c.ks * c.M + m) * c.N + n) = sum[0][0];
+                    }
                 }
             } else {
-                if (a.a_row_ssq) {   // deferred RMSNorm, consumer side: the lane's 4 values belong to row i*16 + (lane & 15)
+                if (a.a_row_ssq) {   // deferred RMSNorm, consumer side: the lane's 4 values belong to row i*16 + (c.lane & 15)
                     const float rs = rstd_s[i * 16 + (c.lane & 15)];
 #pragma unroll
                     for (int tt = 0; tt < TPU; ++tt) { sum[0][tt][0] *= rs; sum[0][tt][1] *= rs; sum[0][tt][2] *= rs; sum[0][tt][3] *= rs; }
@@ -208,6 +223,64 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
             }
         }
         __syncthreads();
+    }
+    if constexpr (TPU == 1) {
+        if (fused) {
+            // ---- the seam.  Every wave's partial stores have been acknowledged by memory (vmcnt(0): write-through stores return when
+            // they are globally visible), the workgroup meets, ONE lane takes a ticket with an agent-scope atomic.  The S-th arrival
+            // knows that the other S - 1 slices are complete: it fetches them past L1 / L2 (sc0 sc1 loads), sums all S slices in slice
+            // order -- its own from registers -- and runs the epilogue of the unsplit kernel.  No spin, no residency assumption: the
+            // workgroups that are not last simply leave.  (Recipe: MI355X_MICROARCH.md, inter-workgroup visibility, "sc0 sc1 stores
+            // and loads both sides" + agent atomics.)  MEASURED (profiles/r03_decode_kernels_ab.txt, run 13): no faster than the
+            // reduce launch -- store acknowledge + ticket + fetch are three memory round trips (o_proj S=2 19.0 vs 18.9 us, S=4 20.8 vs
+            // 19.7; B = 64 decode 5.43 vs 5.26 ms/step on the same box) -- so the engine keeps two launches (VCLA_DS_FUSED=1 selects this form).
+            unsigned* flag = reinterpret_cast<unsigned*>(rstd_s + 64);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* tk = c.tickets + c.group * DS_MAX_CHUNKS + c.chunk;
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag == (unsigned)c.splitk - 1u) {       // workgroup-uniform
+                // all loads of a batch of 4 slices (both units of this wave) are in flight together: one memory round trip per batch;
+                // a slice index >= splitk (or this workgroup's own slice, taken from registers) is masked through the bounds check and reads 0
+                f32x4_t sum[NR][1][1];
+                int um[NR], un[NR];
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) {
+                    const int u = rr * DS_ROUND + c.wave, jj = u / MT, i = u - jj * MT;
+                    um[rr] = i * 16 + (c.lane & 15); un[rr] = (c0 + jj) * 16 + (c.lane >> 4) * 4;
+                    sum[rr][0][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+                for (int s0 = 0; s0 < c.splitk; s0 += 4) {
+                    f32x4_t p[NR][4];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int sl = s0 + q;
+                            const bool ld = rr * DS_ROUND + c.wave < NU && um[rr] < c.M && un[rr] < c.N && sl < c.splitk && sl != c.ks;
+                            const unsigned off = ld ? (unsigned)((((int64_t)sl * c.M + um[rr]) * c.N + un[rr]) * 4) : 0x80000000u;
+                            p[rr][q] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(c.rP, off, 0, 17 /* sc0 sc1 */));
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4_t v = (s0 + q == c.ks) ? mine[rr] : p[rr][q];
+                            sum[rr][0][0][0] += v[0]; sum[rr][0][0][1] += v[1]; sum[rr][0][0][2] += v[2]; sum[rr][0][0][3] += v[3];
+                        }
+                }
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) {
+                    const int u = rr * DS_ROUND + c.wave;
+                    if (u < NU) {
+                        const int jj = u / MT, i = u - jj * MT;
+                        gemm_epilogue<EPI, OutT, 1, 1>(a, sum[rr], i * 16, (c0 + jj) * 16, c.lane);
+                    }
+                }
+                if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+        }
     }
 }
 
@@ -227,6 +300,8 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     const int S = a.ds_splitk > 1 ? a.ds_splitk : 1;
     const int G = gridDim.x / S, g = blockIdx.x / S;           // G groups of S workgroups: one K slice each, the same tiles
     c.splitk = S; c.ks = blockIdx.x - g * S; c.partial = (float*)a.splitk_ws; c.M = a.M; c.N = a.N;
+    c.tickets = S > 1 ? a.ds_tickets : nullptr; c.group = g; c.chunk = 0;
+    c.rP = __builtin_amdgcn_make_buffer_rsrc(a.splitk_ws, 0, S > 1 ? (int)((int64_t)S * a.M * a.N * 4) : 0, 0x00020000);
     const int t_beg = (int)((int64_t)g * units_total / G) * TPU, t_end = (int)((int64_t)(g + 1) * units_total / G) * TPU;
     const int KST = a.K / (32 * KS);                           // stages along K
     c.s_beg = (int)((int64_t)c.ks * KST / S);
@@ -240,7 +315,7 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
     c.voff = c.lane * 16;
     c.a_stage_bytes = (unsigned)(KS * c.mt_c) << 10;
 
-    for (int c0 = t_beg; c0 < t_end; c0 += NTW) {
+    for (int c0 = t_beg; c0 < t_end; c0 += NTW, ++c.chunk) {
         const int nt = (t_end - c0) < NTW ? (t_end - c0) : NTW;     // tiles of this chunk (workgroup-uniform)
         if constexpr (TPU == 2) {
             if (nt == 6) ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
@@ -321,14 +396,14 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(vcla_gemm_args a, int sp
 template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
-    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU) + rstd[64]
+    const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float) + 16;   // 64 KiB (128 KiB for SwiGLU) + rstd[64] + the seam's ticket word
     auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
     VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
     if constexpr (EPI == VCLA_EPI_NONE) {
-        if (a->ds_splitk > 1) {
+        if (a->ds_splitk > 1 && !a->ds_tickets) {
             const int64_t work = (int64_t)a->M * (a->N / 4);
             ds_reduce_kernel<OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
             VCLA_CHECK_LAUNCH("ds_reduce_kernel");
@@ -346,20 +421,41 @@ static int ds_pick_mt(const vcla_gemm_args* a, int units, int grid, hipStream_t 
     return ds_launch<EPI, OutT, 4, FP8>(a, units, grid, s);
 }
 
-// called by vcla_gemm (gemm.hip) for kernel 9; arguments were validated there
-int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
-    const bool fp8 = a->W_q8_frag != nullptr;
+// launch geometry of kernel 9: epilogue units, grid, and whether a split-K launch runs the fused (one-launch) form
+static void ds_plan(const vcla_gemm_args* a, int* units_, int* grid_, bool* fused_) {
     const bool swiglu = a->epilogue == VCLA_EPI_SWIGLU;
     const int tiles = (a->N + 15) / 16;                        // W_frag rows exist up to N_pad (multiple of 128) >= tiles * 16
     const int units = swiglu ? tiles / 2 : tiles;              // SwiGLU: N % 32 == 0
     static const int grid_env = getenv("VCLA_DS_GRID") ? atoi(getenv("VCLA_DS_GRID")) : 256;   // one workgroup per CU
     int grid = units < grid_env ? units : grid_env;
+    bool fused = false;
     if (a->ds_splitk > 1) {   // groups of ds_splitk workgroups share a tile range: keep the launch at one workgroup per CU
         int groups = grid_env / a->ds_splitk;
         if (groups < 1) groups = 1;
         if (groups > units) groups = units;
         grid = groups * a->ds_splitk;
+        // fused split-K needs one arrival counter per (tile group, chunk of its tile range): beyond the 2048 counters the caller
+        // provides the launch falls back to the reduce launch
+        const int per = (units + groups - 1) / groups + 1;      // tile-range boundaries are floor(g * units / G): at most ceil + 1 tiles
+        fused = a->ds_tickets && (per + 3) / 4 <= DS_MAX_CHUNKS && groups * DS_MAX_CHUNKS <= 2048;
     }
+    *units_ = units; *grid_ = grid; *fused_ = fused;
+}
+// for the caller that has to tell the CONSUMER of c_row_ssq which layout this launch writes (engine.hip)
+bool vcla_gemm_dstream_fused(const vcla_gemm_args* a) {
+    int units, grid; bool fused;
+    ds_plan(a, &units, &grid, &fused);
+    return fused;
+}
+
+// called by vcla_gemm (gemm.hip) for kernel 9; arguments were validated there
+int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s) {
+    const bool fp8 = a->W_q8_frag != nullptr;
+    const bool swiglu = a->epilogue == VCLA_EPI_SWIGLU;
+    int units, grid; bool fused;
+    ds_plan(a, &units, &grid, &fused);
+    vcla_gemm_args fb;
+    if (a->ds_tickets && !fused) { fb = *a; fb.ds_tickets = nullptr; a = &fb; }
 #define DS_GO(EPI_, OUT_) return fp8 ? ds_pick_mt<EPI_, OUT_, true>(a, units, grid, s) : ds_pick_mt<EPI_, OUT_, false>(a, units, grid, s)
     if (swiglu) { DS_GO(VCLA_EPI_SWIGLU, bf16_t); }
     if (a->out_f32) { DS_GO(VCLA_EPI_NONE, float); }
