@@ -47,6 +47,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1, help="requests per GPU of the main timed workload (1 = configs[1], 64 = configs[2])")
     ap.add_argument("--steps-b64", type=int, default=5, help="timed steps of the second workload (configs[2], B = 64 per GPU); 0 = skip it")
+    ap.add_argument("--steps-c4", type=int, default=2, help="timed steps of the third workload (BASELINE configs[4] per GPU: fp8 weights, 336 px, "
+                    "B = 32 = 256 / 8); 0 = skip it")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many requests in total, split evenly over the ranks "
                     "(e.g. 256 = north_star's '>= 6x images/sec 1 -> 8 GPUs at batch 256'); replaces --batch, reports scaling = strong")
     ap.add_argument("--prompt-len", type=int, default=128)
@@ -458,6 +460,17 @@ def main():
     if args.steps_b64 > 0 and args.batch == 1 and not strong:
         b64_res = run_workload(64, args.steps_b64, 1)
 
+    c4_res = None
+    if args.steps_c4 > 0 and args.batch == 1 and not strong and not args.fp8 and args.image_size == 224:
+        # BASELINE configs[4], one GPU's share (B = 256 / 8): fp8 weight copies (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe), 336-px
+        # patching (577 ViT tokens).  Runs on the same model object and is undone afterwards (the position embedding returns to its
+        # native values bit for bit, the fp8 copies are dropped) so that the roofline and CPU legs below see the bf16 / 224-px model.
+        model.enable_fp8_decode()
+        model.set_image_size(336)
+        c4_res = run_workload(32, args.steps_c4, 1)
+        model.set_image_size(224)
+        model.enable_fp8_decode(False)
+
     if rank == 0:
         B = args.batch
         cfgd = {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
@@ -481,6 +494,10 @@ def main():
         }
         if b64_res:
             res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
+        if c4_res:
+            res["config4"] = dict(c4_res, dtype="fp8-e4m3 weights (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe), bf16 activations and vision stack",
+                                  workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
+                                           "128 greedy tokens (BASELINE configs[4], one GPU's share)")
         b1 = main_res if B == 1 else None
         b64 = b64_res if b64_res else (main_res if B == 64 else None)
         rl = []

@@ -178,12 +178,6 @@ typedef struct vcla_gemm_args {
        second, fully parallel launch sums the slices in order and applies the epilogue (bias, residual, C, C_frag, c_row_ssq).
        Epilogue NONE only. */
     int ds_splitk;
-    /* with ds_splitk > 1: fold that second launch into the first.  ds_tickets = 2048 arrival counters (8 KiB of device memory the
-       caller zeroes ONCE; the kernel leaves them zero).  Every workgroup writes its fp32 partial tiles through to memory and takes a
-       ticket (agent-scope atomic); the last of the ds_splitk workgroups of a tile group to arrive reads the other slices past its
-       L1 / L2, sums all slices in slice order and runs the epilogue -- no spin, no co-residency requirement, the same values as the
-       two-launch form.  c_row_ssq then has the unsplit layout [M][ceil(N/16)].  NULL = two launches. */
-    unsigned* ds_tickets;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

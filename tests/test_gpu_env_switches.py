@@ -17,7 +17,6 @@ SETTINGS = [
     {"VCLA_DS_DEFER": "0"},                 # a norm launch per RMSNorm instead of the deferred form
     {"VCLA_DS_SPLITK": "2"},
     {"VCLA_DS_GRID": "128"},
-    {"VCLA_DS_FUSED": "1"},                 # split-K o_proj / down_proj in one launch (ticket seam) instead of partial tiles + reduce launch
     {"VCLA_GEMV1X": "0"},                   # runtime-K decode GEMV
     {"VCLA_GEMV_OCC": "1"},
     {"VCLA_ATTN_FLASH": "0"},               # the phased decode attention of round 2
@@ -25,7 +24,8 @@ SETTINGS = [
     {"VCLA_ATTN_MFMA_WHOLE": "0"},
     {"VCLA_ATTN_MFMA_NW": "4"},
     {"VCLA_GEMM_PERSIST": "1"},
-    {"VCLA_GEMM_PF": "1"},                  # L2-prefetch form of the 256 x 256 GEMM
+    {"VCLA_GEMM_PF": "0"},                  # the 256 x 256 GEMM without the L2 prefetch (and without 257-row tiles)
+    {"VCLA_GEMM_XR": "0"},                  # 256-row tiles + a tail launch for the ViT's M = B * 257
     {"VCLA_MFMA128_SPLITK": "0"},
     {"VCLA_TAIL_KERNEL": "7"},
     {"VCLA_TAIL_KERNEL": "8"},

@@ -174,6 +174,27 @@ def test_gemm_mfma128_splitk_single_image_shapes(lib, M, N, K, epi):
     _cmp(f"gemm_mfma128_splitk_f32[{M}x{N}x{K},epi{epi}]", f32, _gemm_ref(a, w, bias, epi, None), atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,epi,fk", [(257 * 3, 768, 192, 0, 4), (257 * 5, 1000, 1024, 1, 4), (257 * 2, 3072, 1024, 3, 4), (257 * 9, 1024, 4096, 2, 5),
+                                          (257 * 64, 1024, 1024, 0, 0), (257 * 64, 4096, 1024, 1, 0), (257 * 32, 1024, 4096, 0, 0), (257 * 7, 2048, 512, 0, 0)])
+def test_gemm_tile257(lib, M, N, K, epi, fk):
+    """M = B * 257 (whole ViT sequences): the 256 x 256 kernel runs 257-row tiles -- the 257th row as a 17th MFMA strip whose other 15
+    rows (the next tile's first rows) are computed and NOT stored -- instead of 256-row rounds + a tail launch.  Every row of every tile
+    against the fp32 reference, bias / activation / in-place residual / SwiGLU / ragged N / fp32 output; fk = 0 is the engine's dispatch."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    ref = _gemm_ref(a, w, bias, epi, res)
+    wp = _pack(w)
+    xd = res.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=xd, out=xd, epilogue=epi, force_kernel=fk)
+    _cmp(f"gemm_tile257[{M}x{N}x{K},epi{epi},k{fk}]", xd, ref, atol=3e-3 if K > 2048 else 2e-3, rtol=8e-3)
+    f32 = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), epilogue=epi, force_kernel=fk, out_f32=True)
+    _cmp(f"gemm_tile257_f32[{M}x{N}x{K},epi{epi},k{fk}]", f32, _gemm_ref(a, w, bias, epi, None), atol=2e-4, rtol=2e-5)
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "gemv"])
 def test_gemm_f32_output_and_identity(lib, kernel):
     """A = I (asymmetric W) catches operand/row-column swaps; fp32 output keeps the full accumulator."""
@@ -944,26 +965,3 @@ def test_gemm_dstream_splitk(lib, M, N, K, S, fp8):
             ref2 = _gemm_ref(bf16r(gamma * x) * rstd, w2, None, 0, None)      # what the kernels compute, in fp32
             _cmp("gemm_dstream_splitk.consumer", got2, ref2, atol=2e-3, rtol=8e-3)
     assert torch.equal(outs[0][0], outs[1][0])
-    # ---- fused form (ds_tickets): one launch, the last workgroup of a tile group to arrive sums the slices in the same order ->
-    # the SAME bits as the two-launch form; row statistics in the unsplit layout [M][N/16]; the counters are left at zero.
-    # Repeated under a competing launch on a second stream (uneven load is where a broken hand-off shows).
-    tickets = torch.zeros(2048, dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream()
-    noise = torch.randn(64 << 20, device=DEV)           # 256 MB: an HBM-bound elementwise pass as the competing load
-    for rep in range(6):
-        if rep % 2:
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    noise.mul_(1.0001).sin_()
-        xf = res.to(DEV, torch.bfloat16)
-        cff = torch.zeros_like(cf) if cf is not None else None
-        ssqf = torch.zeros(M, N // 16, dtype=torch.float32, device=DEV) if N % 16 == 0 else None
-        lib.gemm(None, wp, N, bias=bias.to(DEV), residual=xf, out=xf, force_kernel=9, a_frag=af, m=M, splitk_ws=ws, ds_splitk=S, ds_tickets=tickets,
-                 c_frag=cff, c_frag_gamma=gamma.to(DEV) if with_frag else None, c_row_ssq=ssqf, **kw)
-        torch.cuda.synchronize()
-        assert torch.equal(xf, xd), f"fused split-K differs from the two-launch form (rep {rep})"
-        if cf is not None:
-            assert torch.equal(cff, cf)
-        if ssqf is not None:
-            _cmp("gemm_dstream_splitk.fused.ssq", ssqf.sum(1), (x * x).sum(1), atol=0.0, rtol=1e-5)
-        assert int(tickets.abs().max()) == 0

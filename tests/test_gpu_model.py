@@ -382,6 +382,18 @@ def test_set_image_size_retargets_the_vision_tower(golden_dir):
         m.embed_images(px.cuda())
     with pytest.raises(ValueError):
         m.set_image_size(big + 3)                         # not a multiple of the patch size
+    # every target size is interpolated from the checkpoint's own embedding: two steps == one step, and the native size comes back
+    # bit for bit (bench.py runs its 336-px leg on the same model object and returns to 224 px)
+    bigger = big + cfg.vision.patch_size
+    W3 = {k: v.clone() for k, v in W.items()}
+    extend_position_embedding(W3, cfg.vision.patch_size, bigger)
+    pe = lambda sd: next(v for k, v in sd.items() if k.endswith("vision_model.embeddings.position_embedding.weight")).float().cpu()
+    m.set_image_size(bigger)
+    assert torch.equal(pe(m.state_dict()), pe(W3))
+    m.set_image_size(cfg.vision.image_size)
+    assert torch.equal(pe(m.state_dict()), pe(W))
+    got0 = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda()).logits.float().cpu()
+    assert (got0 - torch.from_numpy(g["logits"]).reshape(got0.shape)).abs().max().item() <= 1e-3
     mb = make_hip_model(cfg, W, torch.bfloat16)
     mb.enable_fp8_decode()
     mb.set_image_size(big)

@@ -235,6 +235,7 @@ def main():
                 a = rnd(M, K)
                 af = _lib.to_frag(a)
                 nb = 2 if tag == "lm_head" else 4
+                nb = int(os.environ.get("VCLA_BENCH_NB", nb))     # 1: the same matrix every launch (<= 256 MB: served from the Infinity Cache)
                 ws = [packw(N, K) for _ in range(nb)]
                 wfs = [to_fragment_major(w) for w in ws]
                 out = torch.empty(M, n_out, dtype=torch.float32 if tag == "lm_head" else torch.bfloat16, device=DEV)
@@ -263,15 +264,6 @@ def main():
                                           c_frag=cfr, c_frag_gamma=gam, c_row_ssq=ssq)
                         line.append(f"S={S_} {timeit(run9s, reps=10) / nb * 1e6:6.1f} us")
                     print(f"M={M:3d} {tag:8s} k9 with deferred-norm outputs, split-K: " + " | ".join(line))
-                    tks = torch.zeros(2048, dtype=torch.int32, device=DEV)
-                    line = []
-                    for S_ in (2, 4, 8):    # the one-launch form: write-through partial tiles + ticket, the last workgroup of a group reduces
-                        def run9f():
-                            for w, wf in zip(ws, wfs):
-                                _lib.gemm(None, w, N, out=out, residual=res, force_kernel=9, a_frag=af, m=M, w_frag=wf, splitk_ws=skws, ds_splitk=S_,
-                                          ds_tickets=tks, c_frag=cfr, c_frag_gamma=gam, c_row_ssq=ssq)
-                        line.append(f"S={S_} {timeit(run9f, reps=10) / nb * 1e6:6.1f} us")
-                    print(f"M={M:3d} {tag:8s} k9 split-K FUSED (ticket seam, one launch):  " + " | ".join(line))
                 qs = [quantize_fp8_rows(w) for w in ws]
                 qfs = [to_fragment_pair_major_fp8(q) for q, _ in qs]
                 def run8q():

@@ -139,7 +139,6 @@ struct vcla_ctx {
         void* q8_ws = nullptr;         // fp8 activation staging of the running prefill (t_fp8_mfma), else NULL
         float* q8s_ws = nullptr;
         int ssq_parts = 0;             // layout of the deferred-RMSNorm row statistics the last producer wrote (see gemm_ds)
-        unsigned* ds_tickets = nullptr; // zeroed arrival counters for the fused split-K streaming GEMMs (decode entry points), else NULL
     } run;
     // cached graphs of the vision stack and of the prefill (fixed launch sequences per shape: ~250 / ~290 launches that are host-bound
     // at B = 1).  Keyed on every pointer and shape the captured launches bake in; see run_macro.
@@ -401,9 +400,7 @@ struct LlamaWs {
     void* q8;       // [M][max(t_hidden, t_inter)] fp8 copy of the activation operand (fp8 MFMA prefill, t_fp8_mfma)
     float* q8s;     // [M] its per-row scales
     int* ticket;    // arrival counter of post_select_kernel (zeroed by the decode loop before its first step)
-    unsigned* ds_tickets;   // 2048 arrival counters of the fused split-K streaming GEMMs (zeroed with `ticket`; the kernels leave them zero)
 };
-#define LLAMA_TICKET_BYTES (256 + 2048 * 4)
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
     const size_t e = esz(ctx);
@@ -420,8 +417,7 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.ids = (int64_t*)b.take((size_t)B * 8);
     t.splitk = b.take(SPLITK_WS_BYTES);
     t.ssq = (float*)b.take((size_t)64 * ((c.t_hidden + 15) / 16) * 4);
-    t.ticket = (int*)b.take(LLAMA_TICKET_BYTES);
-    t.ds_tickets = (unsigned*)((char*)t.ticket + 256);
+    t.ticket = (int*)b.take(256);
     t.q8 = nullptr; t.q8s = nullptr;
     if (c.t_fp8_mfma && (size_t)B * T > 128) {
         t.q8 = b.take(M * (size_t)(c.t_hidden > c.t_inter ? c.t_hidden : c.t_inter));
@@ -476,14 +472,11 @@ static int gemm_ds(vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void*
                    int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr, int splitk = 0) {
     vcla_gemm_args a{};
     if (splitk > 1 && ctx->run.splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
-        static const int fused_env = getenv("VCLA_DS_FUSED") ? atoi(getenv("VCLA_DS_FUSED")) : 0;   // 1: one-launch split-K (ticket seam in gemm_stream.hip; measured slower than the reduce launch)
         a.ds_splitk = splitk; a.splitk_ws = ctx->run.splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
-        a.ds_tickets = fused_env ? ctx->run.ds_tickets : nullptr;
     }
     // partial sums of squares per row this call leaves in c_ssq: the split-K reduce launch writes one per 256 columns (N % 256 ==
     // 0), the in-kernel epilogue one per 16-column tile; the consumer (the next gemm_ds with a_ssq) must be told which
-    a.N = N; a.epilogue = epi;
-    if (c_ssq) ctx->run.ssq_parts = (a.ds_splitk > 1 && (N & 255) == 0 && !vcla_gemm_dstream_fused(&a)) ? N / 256 : N / 16;
+    if (c_ssq) ctx->run.ssq_parts = (a.ds_splitk > 1 && (N & 255) == 0) ? N / 256 : N / 16;
     a.a_row_ssq = a_ssq; a.a_row_ssq_parts = a_parts; a.a_norm_eps = ctx->c.t_eps; a.c_frag_gamma = c_gamma; a.c_row_ssq = c_ssq;
     a.A_frag = A_frag; a.W = W; a.residual = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.C_frag = C_frag;
     a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_f32 = out_f32; a.force_kernel = 9;
@@ -843,8 +836,6 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     ctx->run.splitk_ws = w.splitk;
-    struct TkScope { vcla_ctx* c; explicit TkScope(vcla_ctx* c_, unsigned* t) : c(c_) { c->run.ds_tickets = t; } ~TkScope() { c->run.ds_tickets = nullptr; } } tk_scope(ctx, w.ds_tickets);
-    if (B >= 2) VCLA_CHECK_HIP(hipMemsetAsync(w.ds_tickets, 0, 2048 * 4, (hipStream_t)stream));   // caller memory: zero on every call
     return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
                             logits, ids_out, w);
 }
@@ -877,8 +868,7 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     // The first step's decoder input is embedded here; every later one by the post_select launch that ends the step before it
     // (record the ids, embed them, advance the position: one launch instead of three per step).
     RUN(vcla_embed_splice(w.ids, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, c.t_hidden, c.t_vocab, c.act_dtype, s));
-    VCLA_CHECK_HIP(hipMemsetAsync(w.ticket, 0, LLAMA_TICKET_BYTES, s));
-    struct TkScope { vcla_ctx* c; explicit TkScope(vcla_ctx* c_, unsigned* t) : c(c_) { c->run.ds_tickets = t; } ~TkScope() { c->run.ds_tickets = nullptr; } } tk_scope(ctx, w.ds_tickets);
+    VCLA_CHECK_HIP(hipMemsetAsync(w.ticket, 0, 4, s));
     auto one_step = [&](hipStream_t st) -> int {
         RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0, /*skip_embed=*/true));
         if (c.act_dtype == VCLA_BF16 && c.t_hidden % 8 == 0)

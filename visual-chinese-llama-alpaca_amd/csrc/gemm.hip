@@ -15,6 +15,7 @@
 //   gemm_f32_kernel    fp32 activations (parity mode): classic 64x64x16 LDS-tiled FMA kernel.
 #include "vcla_common.h"
 #include "gemm_epilogue.h"
+#include <type_traits>
 #include <stdlib.h>
 
 int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s);   // gemm_stream.hip (kernel 9)
@@ -202,9 +203,19 @@ extern "C" int vcla_debug_set_timeline(unsigned long long* p) { return (int)hipM
 // of an XCD that share a panel split its lines between them, blockIdx-derived, a pure speed assumption) two K steps before the slab's
 // own DMA is issued, which then finds the lines in L2 or merges with the miss in flight.  All DMA is issued from inline asm and
 // vmcnt is counted by hand (the newest instruction -- the touch -- may stay in flight across the barrier).  One tile per workgroup.
-template <int EPI, typename OutT, bool SGB, bool PF = false>
+// XR = 1 (PF form only): tiles are 257 rows tall.  A ViT activation matrix has M = B * 257 rows (class token + 16 x 16 patches): with 256-row
+// tiles every GEMM of the tower left a 64-row tail at B = 64 (a second, latency-bound launch: 10 us at K = 1024, 46 us at K = 4096 --
+// 12 % of the vision stack); with 257-row tiles the launch is B x N/256 whole tiles and nothing else.  The 257th row rides along as a
+// 17th 16-row MFMA strip of which only row 0 is real: its LDS piece (8 rows, 1 KiB) is one more DMA per K step for wave 0, its A
+// fragment one more ds_read per wave and k-step, and its 16 output tiles are dealt two to each wave (+2 MFMAs on 32, the W fragments
+// are already in registers).  Rows 1..15 of the strip are rows of the NEXT tile or stale LDS: computed, never stored (m_end).
+template <int EPI, typename OutT, bool SGB, bool PF = false, int XR = 0>
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB] (+ 512 B sink, PF)
+    static_assert(XR == 0 || PF, "257-row tiles exist in the PF form only");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB] (+ 512 B sink, PF); XR: A = 34 KiB
+    constexpr int G2_TM = G2_BM + XR;                                      // rows of the output tile
+    constexpr int A_BYTES = XR ? 272 * 128 : G2_TILE_BYTES;                // A region of one stage (XR: 17 strips of 16 rows)
+    constexpr int STAGE = A_BYTES + G2_TILE_BYTES;
     G2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = PF ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -249,17 +260,28 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
     int tile = blockIdx.x;
     int tm, tn;
     tile_assign(tile, tiles_m, tiles_n, 4, tm, tn);
-    int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    int m0 = tm * G2_TM, n0 = tn * G2_BN;
     set_src(m0, n0);
     if constexpr (PF) {
         const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)lds2;
+        // XR: the piece that carries row 256 (rows 256 .. 263 of the tile; 257.. are the next tile's first rows, clamped into the matrix)
+        const bf16_t* xsrc = nullptr;
+        if constexpr (XR) {
+            const int row = 256 + (lane >> 3);
+            int am = m0 + row;
+            if (am >= a.M) am = a.M - 1;
+            xsrc = Ag + (int64_t)am * a.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        }
         auto issue_pf = [&](int kt, int buf) {
-            const unsigned ab = lds_u + buf * 2 * G2_TILE_BYTES, wb = ab + G2_TILE_BYTES;
+            const unsigned ab = lds_u + buf * STAGE, wb = ab + A_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned piece = __builtin_amdgcn_readfirstlane((wave * 4 + i) * 1024);
                 g2_dma16(asrc[i] + (int64_t)kt * GM_BK, ab + piece);
                 g2_dma16(wsrc[i] + (int64_t)kt * GM_BK, wb + piece);
+            }
+            if constexpr (XR) {
+                if (wave == 0) g2_dma16(xsrc + (int64_t)kt * GM_BK, ab + 32 * 1024);
             }
         };
         // touch lines: wave 0 = 64 weight rows (quarter tm & 3 of the 256), wave 1 = 32 activation rows (eighth tn & 7); one line per
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         int prow = wave == 0 ? n0 + 64 * (tm & 3) + lane : m0 + 32 * (tn & 7) + (lane & 31);
         if (wave == 0) prow = prow < n_pad ? prow : n_pad - 1; else prow = prow < a.M ? prow : a.M - 1;
         const bf16_t* pfsrc = wave == 0 ? Wg + (int64_t)prow * a.K : Ag + (int64_t)prow * a.lda;
-        const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 4 * G2_TILE_BYTES + (wave & 1) * 256);
+        const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 2 * STAGE + (wave & 1) * 256);
         auto touch = [&](int kt) {
             if (pf_wave) g2_dma4(pfsrc + (int64_t)(kt < nk ? kt : nk - 1) * GM_BK, sink);
         };
@@ -277,48 +299,68 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        f32x4_t accx[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};   // XR: tiles (2 wm, 2 wm + 1) of the wave's columns, strip 16
         touch(1);
         issue_pf(0, 0);
         touch(2);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (pf_wave) g2_vmcnt<1>(); else g2_vmcnt<0>();      // this wave's pieces of slab kt have landed (the newest touch may not have)
-            __builtin_amdgcn_s_barrier();                        // ... everyone's; and buffer cur^1 is no longer read
-            asm volatile("" ::: "memory");
-            if (kt == 0) G2_STAMP(1);
-            if (kt + 1 < nk) issue_pf(kt + 1, cur ^ 1);
-            touch(kt + 3);
-            const unsigned char* As = lds2 + cur * 2 * G2_TILE_BYTES;
-            const unsigned char* Ws = As + G2_TILE_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t wf[4];
-                bf16x8_t af[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fch));
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * 128 + i * 16 + frow, kk * 4 + fch));
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                if (SGB) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        // the K loop, with the wave's row half as a LITERAL in the 257-row form (the extra strip's W fragments must be literal register
+        // indices, and a wave-uniform branch around its two MFMAs would split the block the sched_group_barrier pattern orders)
+        auto k_loop = [&](auto wmc) {
+            constexpr int WMC = decltype(wmc)::value;
+            const int wmr = WMC < 0 ? wm : WMC;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                if (pf_wave) g2_vmcnt<1>(); else g2_vmcnt<0>();      // this wave's pieces of slab kt have landed (the newest touch may not have)
+                __builtin_amdgcn_s_barrier();                        // ... everyone's; and buffer cur^1 is no longer read
+                asm volatile("" ::: "memory");
+                if (kt == 0) G2_STAMP(1);
+                if (kt + 1 < nk) issue_pf(kt + 1, cur ^ 1);
+                touch(kt + 3);
+                const unsigned char* As = lds2 + cur * STAGE;
+                const unsigned char* Ws = As + A_BYTES;
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8_t wf[4];
+                    bf16x8_t af[8];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fch));
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wmr * 128 + i * 16 + frow, kk * 4 + fch));
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i)
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    if constexpr (XR) {   // strip 16 (row 256 of the tile): tiles 2 WMC, 2 WMC + 1 of this wave's columns -- literal indices, one basic block
+                        const bf16x8_t afx = *reinterpret_cast<const bf16x8_t*>(As + lds_off(256 + frow, kk * 4 + fch));
+                        accx[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * (WMC < 0 ? 0 : WMC)], afx, accx[0][0], 0, 0, 0);
+                        accx[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * (WMC < 0 ? 0 : WMC) + 1], afx, accx[0][1], 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    if (SGB) {
+                        // issue order: 6 fragment reads (4 W + 2 A), then 4 MFMAs per further A read, so every ds_read runs two fragments
+                        // ahead of the MFMAs that consume it (XR: a 13th read, 34 MFMAs)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    #pragma unroll
+                        for (int i = 0; i < 6 + XR; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, XR ? 6 : 8, 0);
+                    }
                 }
+                asm volatile("" ::: "memory");                       // the fragment reads stay on this side of the next barrier
             }
-            asm volatile("" ::: "memory");                       // the fragment reads stay on this side of the next barrier
+        };
+        if constexpr (XR) {
+            if (wm == 0) k_loop(std::integral_constant<int, 0>{}); else k_loop(std::integral_constant<int, 1>{});
+        } else {
+            k_loop(std::integral_constant<int, -1>{});
         }
         g2_vmcnt<0>();                                           // no DMA may land in LDS after the workgroup has given it up
         G2_STAMP(2);
         gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        if constexpr (XR) gemm_epilogue<EPI, OutT, 1, 2>(a, accx, m0 + 256, n0 + wn * 64 + wm * 32, lane, m0 + 257);
         G2_STAMP(3);
 #ifdef VCLA_G2_TIMELINE
         __builtin_amdgcn_s_waitcnt(0);
@@ -1512,6 +1554,12 @@ static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
     return VCLA_OK;
 }
 
+// 257-row tiles (gemm_mfma256_kernel<..., XR = 1>): M is a whole number of ViT sequences (class token + 16 x 16 patches) and the tile
+// grid fills the chip about as well as the 256-row grid would
+static bool vcla_gemm_tile257(const vcla_gemm_args* a) {
+    return a->M >= 257 && a->M % 257 == 0 && a->c_group_rows <= 0;
+}
+
 template <int EPI, typename OutT, bool SGB>
 static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + G2_BM - 1) / G2_BM, tiles_n = (a->N + G2_BN - 1) / G2_BN;
@@ -1521,9 +1569,21 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     static const int pg = getenv("VCLA_GEMM_PERSIST") ? atoi(getenv("VCLA_GEMM_PERSIST")) : 0;   // measured equal: ViT fc1 180 vs 182 us, LLaMA gate/up 1288 vs 1265 us
-    static const int pf = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 0;
+    // PF (default since round 3: B = 64 prefill 98.4 -> 92.4 ms, vision stack 15.8 -> 15.3 ms in the model; VCLA_GEMM_PF=0 = the plain form)
+    static const int pf = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 1;
+    static const int xr_env = getenv("VCLA_GEMM_XR") ? atoi(getenv("VCLA_GEMM_XR")) : 1;   // 0: 256-row tiles also when M % 257 == 0
     const int nt = tiles_m * tiles_n;
-    if (pf && a->K >= 3 * GM_BK) {
+    if (pf && SGB && a->K >= 3 * GM_BK) {   // force_kernel 5 (SGB = false) stays the plain form: both forms remain under test
+        if (xr_env && vcla_gemm_tile257(a)) {   // M = B * 257 (the ViT's token count): 257-row tiles, no ragged tail
+            auto kx = gemm_mfma256_kernel<EPI, OutT, SGB, true, 1>;
+            const size_t ldx = 2 * (272 * 128 + G2_TILE_BYTES) + 512;   // 132.5 KiB
+            static bool attr_x[VCLA_MAX_DEVICES] = {};
+            { const int rc_ = vcla_raise_dyn_lds((const void*)kx, ldx, attr_x); if (rc_) return rc_; }
+            const int tmx = a->M / 257;
+            kx<<<tmx * tiles_n, 512, ldx, s>>>(*a, tmx, tiles_n, n_pad);
+            VCLA_CHECK_LAUNCH("gemm_mfma256_kernel<PF, 257>");
+            return VCLA_OK;
+        }
         auto kpf = gemm_mfma256_kernel<EPI, OutT, SGB, true>;
         static bool attr_pf[VCLA_MAX_DEVICES] = {};
         { const int rc_ = vcla_raise_dyn_lds((const void*)kpf, lds + 512, attr_pf); if (rc_) return rc_; }
@@ -1650,6 +1710,15 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                 vcla_gemm_args head = *a, tail = *a;
                 head.M = a->M - rem;
                 if (prefer_256(&head)) {
+                    static const int pf_env = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 1;
+                    static const int xr_env = getenv("VCLA_GEMM_XR") ? atoi(getenv("VCLA_GEMM_XR")) : 1;
+                    if (pf_env && xr_env && vcla_gemm_tile257(a) && a->K >= 3 * GM_BK) {
+                        // M = B * 257: ONE launch of 257-row tiles instead of whole 256-row rounds + a tail launch
+                        head = *a;
+                        head.force_kernel = 4;
+                        head.post_norm_gamma = nullptr;                          // the wrapper normalises all of C afterwards
+                        return gemm_impl(&head, dtype, stream);
+                    }
                     const size_t es = 2, cs = a->out_f32 ? 4 : 2;
                     tail.M = rem;
                     tail.A = (const char*)a->A + (size_t)head.M * a->lda * es;

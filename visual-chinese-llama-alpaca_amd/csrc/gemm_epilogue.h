@@ -18,7 +18,7 @@ __device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
 // acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
 // columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
 template <int EPI, typename OutT, int MI, int NJ = 4>
-__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane, int m_end = 0x7fffffff) {
     const int mrow = lane & 15, nq = (lane >> 4) * 4;
     OutT* Cg = (OutT*)a.C;
     constexpr bool kF32 = sizeof(OutT) == 4;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = mw + i * 16 + mrow;
-                if (m >= a.M) continue;                        // the 4 lanes that exchange data share m
+                if (m >= a.M || m >= m_end) continue;          // the 4 lanes that exchange data share m (m_end: rows of a tile strip that belong to the next tile)
                 const int64_t crow = remap_row(a, m);
                 const float ascale = a.a_scale ? a.a_scale[m] : 1.f;
 #pragma unroll
@@ -113,7 +113,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw + i * 16 + mrow;
-        if (m >= a.M) continue;
+        if (m >= a.M || m >= m_end) continue;
         const int64_t crow = remap_row(a, m);
         const float ascale = a.a_scale ? a.a_scale[m] : 1.f;   // fp8 activations: per-row scale (kernel 10)
 #pragma unroll
@@ -135,7 +135,9 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                 // fragment-major copy for the next streaming GEMM (its K index = this output column n): the lane's 4
                 // consecutive columns are half of one 8-element operand fragment -> one 8-byte store (n_out % 32 == 0)
                 const int mt_c = (a.M + 15) >> 4;
-                bf16_t* fp = (bf16_t*)a.C_frag + ((((int64_t)(n >> 5) * mt_c + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7);
+                // 32-bit element offset (C_frag belongs to kernel 9: M <= 64 rows -> < 2^31 elements for any N): no 64-bit temporaries
+                const unsigned fo = ((((unsigned)(n >> 5) * (unsigned)mt_c + (unsigned)(m >> 4)) * 64u + (unsigned)((n & 31) >> 3) * 16u + (unsigned)(m & 15)) << 3) + (unsigned)(n & 7);
+                bf16_t* fp = (bf16_t*)a.C_frag + fo;
                 float f[4] = {v[0], v[1], v[2], v[3]};
                 if (a.c_frag_gamma) {
 #pragma unroll

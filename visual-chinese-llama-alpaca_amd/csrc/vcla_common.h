@@ -43,9 +43,6 @@ int vcla_fail(int code, const char* fmt, ...);
 int vcla_sample_launch(float* logits, int64_t ld, int B, int V, int n_hist, const int32_t* n_hist_dev, const vcla_sample_args* a,
                        int64_t* out, hipStream_t s);
 
-// gemm_stream.hip: does this kernel-9 launch run the fused (one-launch) split-K form?  (decides the layout of c_row_ssq)
-bool vcla_gemm_dstream_fused(const vcla_gemm_args* a);
-
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): raise it once per device a kernel instantiation
 // is launched on (`done` = a static flag array of that instantiation), not once per process
 #define VCLA_MAX_DEVICES 32

@@ -351,9 +351,15 @@ class VisualCLAModel:
             raise ValueError(f"image_size {image_size} is not a multiple of the patch size {v['patch_size']}")
         # only the position embedding depends on the resolution: interpolate it on the host (the same arithmetic as the oracle /
         # the reference helper) and swap that one tensor -- every other packed tensor, incl. the fp8 / fragment-major copies, stays
+        # Always interpolate FROM the embedding the checkpoint came with (kept on first use): going 224 -> 336 -> 448 equals 224 -> 448,
+        # and returning to the native size restores the original values bit for bit.
         key = "vision_model.embeddings.position_embedding.weight"
-        sd = {key: self._packed["vit.pos"].detach().float().cpu()}
-        extend_position_embedding(sd, v["patch_size"], image_size)
+        if getattr(self, "_pos_native", None) is None:
+            self._pos_native = (v["image_size"], self._packed["vit.pos"])
+        native_size, native_pos = self._pos_native
+        sd = {key: native_pos.detach().float().cpu()}
+        if image_size != native_size:
+            extend_position_embedding(sd, v["patch_size"], image_size)
         v["image_size"] = image_size
         self.vision_model.config.image_size = image_size
         self._packed["vit.pos"] = sd[key].to(device=self._device, dtype=torch.float32).contiguous()
