@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] weight path: fp8 (e4m3) decode weights, bf16 activations")
+    ap.add_argument("--fp8-kv", type=int, default=1, help="with the fp8 weight path (--fp8 and the config4 leg): 1 = the K/V cache holds e4m3 bytes too, 0 = bf16 cache")
     ap.add_argument("--image-size", type=int, default=224, help="336 = BASELINE configs[4] patching (577 ViT tokens, position embedding grown bicubically)")
     ap.add_argument("--sample", action="store_true", help="decode under the reference's DEFAULT_GENERATION_CONFIG (sampling + "
                     "penalties, on-device sampler) instead of greedy; a side measurement, not BASELINE's metric")
@@ -244,7 +245,7 @@ def fp8_gemm_roofline(model, M: int = 8192, n_rep: int = 5):
             "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * nl}
 
 
-def step_rooflines(b1, b64, cfgd, fp8: bool):
+def step_rooflines(b1, b64, cfgd, fp8: bool, kv8: bool = False):
     """Whole-step figures, so the line cannot quote only its best kernel: decode bytes per step = all LLaMA linear weights +
     lm_head read once (13.36 GB bf16 / 6.68 GB fp8, shared by the batch) + B * ctx * 512 KiB of KV cache (ctx = mean context
     over the decode steps); vision flops = 179.2 GF per image at 224 px (ViT 162.0 + resampler 16.64 + projection 0.54)."""
@@ -256,7 +257,7 @@ def step_rooflines(b1, b64, cfgd, fp8: bool):
         if not br:
             continue
         B = br["batch_per_gpu"]
-        bytes_step = w_bytes + B * ctx * KV_BYTES_PER_TOKEN
+        bytes_step = w_bytes + B * ctx * KV_BYTES_PER_TOKEN / (2 if (fp8 and kv8) else 1)
         ach = bytes_step / (br["breakdown_ms"]["decode_ms_per_token_step"] * 1e-3) / 1e9
         out.append({"bound": "hbm", "kernel": f"whole decode step, {tag} per GPU (all kernels + launch gaps)", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -393,7 +394,7 @@ def main():
     model.tokenizer = stub_tokenizer()
     model.image_at_head = False
     if args.fp8:
-        model.enable_fp8_decode()
+        model.enable_fp8_decode(kv_cache=bool(args.fp8_kv))
     if args.image_size != 224:
         model.set_image_size(args.image_size)
 
@@ -465,7 +466,7 @@ def main():
         # BASELINE configs[4], one GPU's share (B = 256 / 8): fp8 weight copies (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe), 336-px
         # patching (577 ViT tokens).  Runs on the same model object and is undone afterwards (the position embedding returns to its
         # native values bit for bit, the fp8 copies are dropped) so that the roofline and CPU legs below see the bf16 / 224-px model.
-        model.enable_fp8_decode()
+        model.enable_fp8_decode(kv_cache=bool(args.fp8_kv))
         model.set_image_size(336)
         c4_res = run_workload(32, args.steps_c4, 1)
         model.set_image_size(224)
@@ -488,14 +489,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 weights: W8A16 in the decode steps (dequantised in registers), W8A8 on the fp8 MFMA pipe in the "
-                                                  "prefill (per-row e4m3 activations); bf16 activations elsewhere, fp32 accumulate"),
+                                                  "prefill (per-row e4m3 activations)" + ("; e4m3 K/V cache (unit scale)" if args.fp8_kv else "") +
+                                                  "; bf16 activations elsewhere, fp32 accumulate"),
             "data": "synthetic (random-init 7B weights, N(0,1) pixels, synthetic ids)", "config": cfgd,
             "breakdown_ms": main_res.get("breakdown_ms"),
         }
         if b64_res:
             res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
         if c4_res:
-            res["config4"] = dict(c4_res, dtype="fp8-e4m3 weights (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe), bf16 activations and vision stack",
+            res["config4"] = dict(c4_res, dtype="fp8-e4m3 weights (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe)" + (", e4m3 K/V cache" if args.fp8_kv else "") +
+                                  ", bf16 activations and vision stack",
                                   workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
                                            "128 greedy tokens (BASELINE configs[4], one GPU's share)")
         b1 = main_res if B == 1 else None
@@ -516,7 +519,7 @@ def main():
             res["roofline"] = r
             if r:
                 rl.append(r)
-        rl += step_rooflines(b1, b64, cfgd, args.fp8)
+        rl += step_rooflines(b1, b64, cfgd, args.fp8, bool(args.fp8_kv))
         res["rooflines"] = rl
         if not args.no_cpu_baseline and world == 1 and args.image_size == 224:   # the CPU baseline is reported by the N=1 run only
             try:

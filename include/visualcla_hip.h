@@ -73,6 +73,10 @@ enum {
 
 /* activation dtypes */
 enum { VCLA_F32 = 0, VCLA_BF16 = 1 };
+/* OR-ed into the `dtype` argument of vcla_rope_kv_append / vcla_attn_decode_fused (with VCLA_BF16 only): the K / V cache holds
+   OCP fp8 (e4m3fn) values, unit scale -- one byte per element, [B, H, ctx_max, d] bytes per slab.  The lossy companion of the
+   fp8 weight path (BASELINE configs[4]): at B = 64 the bf16 cache is as many bytes per decode step as the fp8 weights. */
+#define VCLA_KV_FP8 0x100
 
 /* GEMM epilogues (applied to acc + bias) */
 enum {
@@ -247,7 +251,8 @@ int vcla_embed_splice(const int64_t* ids, const void* table, const void* image_e
 
 /* RoPE on q (in place) and k of a fused qkv buffer [B*T, 3*H*d], append k / v to the cache.
    position of row t = pos0 + (pos_dev ? *pos_dev : 0) + t.  cos/sin tables fp32 [max_pos, d/2].
-   k_cache / v_cache: [B, H, ctx_max, d]. */
+   k_cache / v_cache: [B, H, ctx_max, d].  dtype | VCLA_KV_FP8: the cache receives e4m3 bytes and the rotated k is ALSO written back
+   into the qkv buffer (bf16), so that a prefill can attend over the exact bf16 rows while the cache keeps the 1-byte copies. */
 int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
                         int B, int T, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev, int dtype,
                         void* stream);
@@ -255,7 +260,9 @@ int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* co
 /* Fused decode-step attention for every (sequence, head): RoPE on q and the new k of the fused qkv row [B, 3*H*d],
    append k / v to the cache at position pos0 + (pos_dev ? *pos_dev : 0), softmax(scale q K^T) V over keys 0..pos.
    out [B, H*d]; out_frag != 0 (bf16 only, B <= 64): out is written in the fragment-major layout of vcla_gemm_args.A_frag
-   ([H*d/32][ceil(B/16)][64][8]) for the streaming o_proj GEMM.  key_mask [B, key_mask_ld] optional. */
+   ([H*d/32][ceil(B/16)][64][8]) for the streaming o_proj GEMM.  key_mask [B, key_mask_ld] optional.
+   dtype | VCLA_KV_FP8 (d = 128 or 64): the cache rows are e4m3 bytes -- 16 elements per 16-byte lane load, converted in
+   registers; the new token's k / v enter the cache, and this step's own softmax, as their e4m3 roundings. */
 int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
                            void* out, int B, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev,
                            const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, int out_frag, void* stream);
@@ -314,6 +321,9 @@ typedef struct vcla_model_cfg {
     /* 1: decoder GEMMs with more than 128 rows (prefill) whose weight has fp8 copies registered ("<name>.q8" + ".s8") run on the
        fp8 MFMA pipe, activations quantised per row on the fly (BASELINE configs[4]); 0: bf16 MFMA */
     int t_fp8_mfma;
+    /* 1 (bf16 activations only): the LLaMA K / V cache holds e4m3 bytes (VCLA_KV_FP8): vcla_kv_cache_bytes halves, prefill (pos0 = 0
+       only) attends over the bf16 rows of its own qkv buffer, decode steps read the 1-byte cache */
+    int t_kv_fp8;
 } vcla_model_cfg;
 
 typedef struct vcla_ctx vcla_ctx;

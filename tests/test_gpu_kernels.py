@@ -453,6 +453,88 @@ def test_attn_decode_fused(lib, dtype, B, H, d, pos):
     assert torch.equal(kc_d[:, :, :pos].float().cpu(), kc[:, :, :pos]) and torch.equal(kc_d[:, :, pos + 1:].float().cpu(), kc[:, :, pos + 1:])
 
 
+KV_FP8 = 0x100     # include/visualcla_hip.h VCLA_KV_FP8
+
+
+def _fp8rt(t):
+    """e4m3fn rounding (what the cache stores) of a float tensor, and the bytes"""
+    q = t.float().to(torch.float8_e4m3fn)
+    return q.float(), q.view(torch.uint8)
+
+
+@pytest.mark.parametrize("B,H,d,pos,frag", [(1, 4, 128, 0, 0), (2, 3, 128, 37, 0), (64, 32, 128, 191, 1), (3, 2, 64, 70, 0), (16, 32, 128, 254, 1), (2, 2, 128, 300, 0)])
+def test_attn_decode_fused_fp8_cache(lib, B, H, d, pos, frag):
+    """VCLA_KV_FP8: the cache rows are e4m3 bytes (16 elements per 16-byte lane load, converted in registers).  Reference = fp32 attention
+    over the DEQUANTISED cache + the e4m3 rounding of the new token's roped key / value -- the only rounding the kernel adds on top is the
+    bf16 output; the appended bytes must equal torch's own float8_e4m3fn conversion."""
+    from visualcla.weights import rope_tables
+    ctx = max(64, (pos + 64) // 64 * 64)
+    g = torch.Generator().manual_seed(B + H + d + pos)
+    qkv = bf16r(torch.randn(B, 3, H, d, generator=g))
+    kc, kc_b = _fp8rt(torch.randn(B, H, ctx, d, generator=g))
+    vc, vc_b = _fp8rt(torch.randn(B, H, ctx, d, generator=g))
+    km = torch.ones(B, ctx, dtype=torch.int32)
+    if pos > 3:
+        km[0, 1:3] = 0
+    cos, sin = rope_tables(1024, d, 10000.0)
+    c, s = O.llama_rope_tables(torch.tensor([pos]), d, 10000.0, torch.float32)
+    c, s = bf16r(c), bf16r(s)
+    q = bf16r(O.apply_rope(qkv[:, 0][:, :, None, :], c, s))          # [B,H,1,d]
+    kn, kn_b = _fp8rt(bf16r(O.apply_rope(qkv[:, 1][:, :, None, :], c, s)))
+    vn, vn_b = _fp8rt(qkv[:, 2][:, :, None, :])
+    K = torch.cat([kc[:, :, :pos], kn], dim=2)
+    V = torch.cat([vc[:, :, :pos], vn], dim=2)
+    ref = _attn_ref(q, K, V, 1 / math.sqrt(d), True, km)
+    kc_d, vc_d = kc_b.to(DEV).contiguous(), vc_b.to(DEV).contiguous()
+    qkv_d = qkv.reshape(B, 3 * H * d).to(DEV, torch.bfloat16).contiguous()
+    out = torch.zeros((H * d) // 32, (B + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if frag else torch.empty(B, H * d, dtype=torch.bfloat16, device=DEV)
+    dev_part = min(2, pos)
+    pos_dev = torch.tensor([dev_part], dtype=torch.int32, device=DEV)
+    cos_d, sin_d, km_d = cos.to(DEV), sin.to(DEV), km.to(DEV)
+    L = lib.load()
+    lib.check(L.vcla_attn_decode_fused(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(),
+                                       out.data_ptr(), B, H, d, ctx, pos - dev_part, pos_dev.data_ptr(), km_d.data_ptr(), ctx,
+                                       1 / math.sqrt(d), lib.dtype_code(torch.bfloat16) | KV_FP8, frag, lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = lib.from_frag(out, B) if frag else out
+    _cmp(f"attn_decode_fused_fp8kv[B{B}H{H}d{d}pos{pos}]", got.reshape(B, 1, H * d), ref, atol=1.5e-2)
+    assert torch.equal(kc_d[:, :, pos].cpu(), kn_b[:, :, 0]) and torch.equal(vc_d[:, :, pos].cpu(), vn_b[:, :, 0])
+    assert torch.equal(kc_d[:, :, :pos].cpu(), kc_b[:, :, :pos]) and torch.equal(vc_d[:, :, pos + 1:].cpu(), vc_b[:, :, pos + 1:])
+    with pytest.raises((ValueError, lib.VclaError)):     # fp32 activations have no fp8-cache form
+        lib.check(L.vcla_attn_decode_fused(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(), out.data_ptr(), B, H, d,
+                                           ctx, pos, None, None, 0, 1 / math.sqrt(d), lib.dtype_code(torch.float32) | KV_FP8, 0, lib.stream_ptr()))
+
+
+def test_rope_kv_append_fp8_cache(lib):
+    """prefill side of VCLA_KV_FP8: q and k rotated IN PLACE in the qkv buffer (bf16, what the prompt's own attention reads), the cache
+    receives the e4m3 bytes of the rotated k and of v"""
+    from visualcla.weights import rope_tables
+    B, T, H, d, ctx, pos0 = 2, 5, 3, 128, 64, 0
+    g = torch.Generator().manual_seed(77)
+    qkv = bf16r(torch.randn(B, T, 3, H, d, generator=g))
+    cos, sin = rope_tables(256, d, 10000.0)
+    c, s = O.llama_rope_tables(torch.arange(pos0, pos0 + T), d, 10000.0, torch.float32)
+    c, s = bf16r(c), bf16r(s)
+    qr = bf16r(O.apply_rope(qkv[:, :, 0].permute(0, 2, 1, 3), c, s))      # [B,H,T,d]
+    kr = bf16r(O.apply_rope(qkv[:, :, 1].permute(0, 2, 1, 3), c, s))
+    qkv_d = qkv.reshape(B * T, 3 * H * d).to(DEV, torch.bfloat16).contiguous()
+    kc_d = torch.full((B, H, ctx, d), 0x55, dtype=torch.uint8, device=DEV)
+    vc_d = torch.full((B, H, ctx, d), 0x55, dtype=torch.uint8, device=DEV)
+    L = lib.load()
+    cos_d, sin_d = cos.to(DEV), sin.to(DEV)        # (named: a temporary would be freed -- and its block reused -- before the launch)
+    lib.check(L.vcla_rope_kv_append(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(), B, T, H, d, ctx, pos0,
+                                    None, lib.dtype_code(torch.bfloat16) | KV_FP8, lib.stream_ptr()))
+    torch.cuda.synchronize()
+    back = qkv_d.float().cpu().view(B, T, 3, H, d)
+    _cmp("rope_kv_fp8.q_in_place", back[:, :, 0].permute(0, 2, 1, 3), qr, atol=0.0)
+    _cmp("rope_kv_fp8.k_in_place", back[:, :, 1].permute(0, 2, 1, 3), kr, atol=0.0)
+    _cmp("rope_kv_fp8.v_untouched", back[:, :, 2], qkv[:, :, 2], atol=0.0)
+    kb, vb = _fp8rt(kr)[1], _fp8rt(qkv[:, :, 2].permute(0, 2, 1, 3))[1]
+    nk, nv = int((kc_d[:, :, :T].cpu() != kb).sum()), int((vc_d[:, :, :T].cpu() != vb).sum())
+    assert nk == 0 and nv == 0, (nk, nv)
+    assert int((kc_d[:, :, T:] != 0x55).sum()) == 0 and int((vc_d[:, :, T:] != 0x55).sum()) == 0
+
+
 # ------------------------------------------------------------------ MFMA flash attention (bf16)
 @pytest.mark.parametrize("B,H,Tq,Tk,D,causal", [
     (2, 3, 257, 257, 64, False), (1, 2, 64, 321, 64, False), (2, 4, 48, 48, 128, True), (1, 2, 130, 130, 128, True),

@@ -370,9 +370,11 @@ def main():
         H, d = 32, 128
         cos, sin = (t.to(DEV) for t in rope_tables(1024, d, 10000.0))
         for B, ctx_max, poss in ((64, 256, (128, 192, 254)), (32, 704, (640,)), (1, 256, (128, 192, 254))):
-            nbuf = 4 if B > 1 else 32
-            kcs = [rnd(B, H, ctx_max, d) for _ in range(nbuf)]
-            vcs = [rnd(B, H, ctx_max, d) for _ in range(nbuf)]
+            nbuf = int(os.environ.get("VCLA_BENCH_NBUF", 4 if B > 1 else 32))   # 1: the same K / V buffers every launch (<= 256 MB: Infinity-Cache resident)
+            kv8 = int(os.environ.get("VCLA_BENCH_KV8", "0"))        # 1: e4m3 cache rows (VCLA_KV_FP8)
+            mk = (lambda: (torch.randn(B, H, ctx_max, d, device=DEV)).to(torch.float8_e4m3fn).view(torch.uint8)) if kv8 else (lambda: rnd(B, H, ctx_max, d))
+            kcs = [mk() for _ in range(nbuf)]
+            vcs = [mk() for _ in range(nbuf)]
             qkv = rnd(B, 3 * H * d)
             frag = 1 if 2 <= B <= 64 else 0
             out = torch.zeros((H * d) // 32, (B + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if frag else torch.empty(B, H * d, dtype=torch.bfloat16, device=DEV)
@@ -381,10 +383,10 @@ def main():
                 def run():
                     for kc, vc in zip(kcs, vcs):
                         _lib.check(L.vcla_attn_decode_fused(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
-                                                            B, H, d, ctx_max, pos, None, None, 0, 1 / math.sqrt(d), _lib.dtype_code(torch.bfloat16), frag,
+                                                            B, H, d, ctx_max, pos, None, None, 0, 1 / math.sqrt(d), _lib.dtype_code(torch.bfloat16) | (0x100 if kv8 else 0), frag,
                                                             _lib.stream_ptr()))
                 t = timeit(run, reps=10) / nbuf
-                by = B * H * pos * d * 2 * 2
+                by = B * H * pos * d * 2 * (1 if kv8 else 2)
                 print(f"attndec B={B:3d} ctx={pos:4d}  {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s of K/V rows  ({by/t/8e12*100:5.1f}% of HBM peak)")
             del kcs, vcs
     if "vitattn" in which:

@@ -325,8 +325,42 @@ __device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b) {
     return acc;
 }
 
-template <int D, int NW, bool MASK>
-__global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+// ---- fp8 (e4m3fn, unit scale) cache rows: 16 elements per 16-byte lane chunk
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 values that are exactly representable in bf16 (every e4m3 value is) -> packed bf16 pair: the high halves, one v_perm_b32
+__device__ __forceinline__ uint32_t hi16_pair(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+// 16 bf16 (q: two packed quads of dwords) x 16 e4m3 (k) -> fp32: cvt_pk_f32_fp8 + v_perm_b32 + v_dot2c_f32_bf16 per pair
+__device__ __forceinline__ float dot16_fp8(const u32x4_t& q0, const u32x4_t& q1, const u32x4_t& k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(k[w], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(k[w], true);
+        const uint32_t ka = hi16_pair(lo.x, lo.y), kb = hi16_pair(hi.x, hi.y);
+        const uint32_t qa = w < 2 ? q0[2 * w] : q1[2 * w - 4], qb = w < 2 ? q0[2 * w + 1] : q1[2 * w - 3];
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, qa), __builtin_bit_cast(bf16x2_t, ka), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, qb), __builtin_bit_cast(bf16x2_t, kb), acc, false);
+    }
+    return acc;
+}
+__device__ __forceinline__ void fp8x16_to_f32(const u32x4_t& t, float* v) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(t[w], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(t[w], true);
+        v[4 * w] = lo.x; v[4 * w + 1] = lo.y; v[4 * w + 2] = hi.x; v[4 * w + 3] = hi.y;
+    }
+}
+// e4m3 rounding of one value: the byte, and the value it decodes to
+__device__ __forceinline__ unsigned char f32_to_fp8(float x) { return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff); }
+__device__ __forceinline__ float fp8_round(float x) {
+    const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false), false);
+    return r.x;
+}
+
+template <int D, int NW, bool MASK, bool KV8 = false>
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, void* __restrict__ kc_, void* __restrict__ vc_,
                                                                 const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                                 bf16_t* __restrict__ out, int H, int ctx_max, int pos0,
                                                                 const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
@@ -334,7 +368,13 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     // U keys per lane group and batch.  The 2-wave form (batch decode: thousands of workgroups, 4 waves per SIMD) keeps 2 x 4 rows of K
     // and V per lane in flight; the 4-wave form (a few dozen latency-bound workgroups: B = 1) 2 x 8 -- with D = 128 its 16 groups
     // then have the first 256 keys of the context requested before the RoPE phase ends
-    constexpr int LPK = D / 8, KPW = 64 / LPK, KPB = NW * KPW, HALF = D / 2, U = NW == 2 ? 4 : 8, NT = NW * 64;
+    // KV8: the cache holds e4m3 bytes -- E = 16 elements per 16-byte chunk, half the lanes per row, twice the keys per wave load
+    // (half the lane loads per batch: a wave load then covers the same number of KEYS as in the bf16 form, and the 16 output / 16 value
+    // registers per lane fit next to the rings without spilling -- with U = 4 the 2-wave form spilled 55 registers and ran 64 us
+    // instead of 34 at B = 64, context 192)
+    constexpr int E = KV8 ? 16 : 8, ESZ = KV8 ? 1 : 2, LPK = D / E, KPW = 64 / LPK, KPB = NW * KPW, HALF = D / 2, NT = NW * 64;
+    constexpr int U = (NW == 2 ? 4 : 8) / (KV8 ? 2 : 1);
+    static_assert(LPK >= 4, "a lane group is at least a quad (group_sum)");
     // one LDS object (16-byte aligned carve): roped q as packed bf16 [D/2 dwords], new key / value fp32 [D] each, wave partials
     __shared__ __attribute__((aligned(16))) float smem[D / 2 + 2 * D + NW * (D + 2)];
     uint32_t* qpk = reinterpret_cast<uint32_t*>(smem);       // [D/2]  bf16 pairs (2e, 2e+1)
@@ -346,8 +386,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     const int pos = pos0 + (pos_dev ? *pos_dev : 0);         // position of the new token = number of cached keys
     const int HD = H * D;
     const bf16_t* row = qkv + (int64_t)b * 3 * HD;
-    bf16_t* kbase = kc + ((int64_t)b * H + h) * ctx_max * D;
-    bf16_t* vbase = vc + ((int64_t)b * H + h) * ctx_max * D;
+    unsigned char* kbase = (unsigned char*)kc_ + ((int64_t)b * H + h) * ctx_max * D * ESZ;
+    unsigned char* vbase = (unsigned char*)vc_ + ((int64_t)b * H + h) * ctx_max * D * ESZ;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
     const int c = lane % LPK, grp = wave * KPW + lane / LPK;   // chunk of the row, lane group within the workgroup
 
@@ -366,13 +406,13 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     // are unconditional, so the loop carries no branch around a load and the compiler emits counted waits
     // buffer loads (uniform descriptor per (b, h) slab + one 32-bit offset per row, non-temporal): no 64-bit address arithmetic in
     // the loop, and the policy bit survives (the plain nontemporal load builtin lost it once fences were nearby)
-    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(kbase, 0, ctx_max * D * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vbase, 0, ctx_max * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(kbase, 0, ctx_max * D * ESZ, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vbase, 0, ctx_max * D * ESZ, 0x00020000);
 #define FD_LOAD(KB_, VB_, MB_, t_)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
         int j_ = grp + ((t_) * U + u) * KPB;                                                                         \
         j_ = j_ < pos ? j_ : last;                                                                                   \
-        const unsigned off_ = (unsigned)(j_ * D + c * 8) * 2u;                                                       \
+        const unsigned off_ = (unsigned)(j_ * D * ESZ + c * 16);                                                     \
         KB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rK, off_, 0, 2 /* nt */));         \
         VB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, off_, 0, 2 /* nt */));         \
         MB_[u] = MASK ? km[j_] : 1;                                                                                  \
@@ -389,14 +429,25 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         const float r0 = Act<bf16_t>::rnd(k0 * cr - k1 * sr), r1 = Act<bf16_t>::rnd(k1 * cr + k0 * sr);
         reinterpret_cast<bf16_t*>(qpk)[tid] = f2bf(a0);
         reinterpret_cast<bf16_t*>(qpk)[tid + HALF] = f2bf(a1);
-        knew[tid] = r0; knew[tid + HALF] = r1;
-        kbase[(int64_t)pos * D + tid] = f2bf(r0);
-        kbase[(int64_t)pos * D + tid + HALF] = f2bf(r1);
+        if constexpr (KV8) {     // the cache -- and this step's own score -- see the e4m3 rounding of the new key
+            knew[tid] = fp8_round(r0); knew[tid + HALF] = fp8_round(r1);
+            kbase[(int64_t)pos * D + tid] = f32_to_fp8(r0);
+            kbase[(int64_t)pos * D + tid + HALF] = f32_to_fp8(r1);
+        } else {
+            knew[tid] = r0; knew[tid + HALF] = r1;
+            reinterpret_cast<bf16_t*>(kbase)[(int64_t)pos * D + tid] = f2bf(r0);
+            reinterpret_cast<bf16_t*>(kbase)[(int64_t)pos * D + tid + HALF] = f2bf(r1);
+        }
     } else {
         for (int i = tid - HALF; i < D; i += NT - HALF) {    // the threads past the RoPE lanes move the value row
             const bf16_t v = row[2 * HD + h * D + i];
-            vnew[i] = bf2f(v);
-            vbase[(int64_t)pos * D + i] = v;
+            if constexpr (KV8) {
+                vnew[i] = fp8_round(bf2f(v));
+                vbase[(int64_t)pos * D + i] = f32_to_fp8(bf2f(v));
+            } else {
+                vnew[i] = bf2f(v);
+                reinterpret_cast<bf16_t*>(vbase)[(int64_t)pos * D + i] = v;
+            }
         }
     }
     // LDS-only release / acquire around a bare s_barrier: __syncthreads() would also drain vmcnt (the cache-append stores AND,
@@ -404,19 +455,21 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(qpk + c * 4);     // this lane's 8 q values, packed bf16
+    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(qpk + c * (E / 2));      // this lane's first 8 q values, packed bf16
+    u32x4_t qv1 = qv;                                                             // KV8: values 8 .. 15 of the chunk
+    if constexpr (KV8) qv1 = *reinterpret_cast<const u32x4_t*>(qpk + c * (E / 2) + 4);
     const float sl2 = scale * 1.44269504088896340736f;                     // scores live in the log2 domain
 
-    float m_run = -INFINITY, l_run = 0.f, o[8];
+    float m_run = -INFINITY, l_run = 0.f, o[E];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int e = 0; e < E; ++e) o[e] = 0.f;
 #define FD_COMPUTE(KB_, VB_, MB_, t_)                                                                                \
     {                                                                                                                \
         float s_[U];                                                                                                 \
         float mb_ = -INFINITY;                                                                                       \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
             const int j_ = grp + ((t_) * U + u) * KPB;                                                               \
-            const float d_ = group_sum<LPK>(dot8_bf16(qv, KB_[u]));                                                  \
+            const float d_ = group_sum<LPK>(KV8 ? dot16_fp8(qv, qv1, KB_[u]) : dot8_bf16(qv, KB_[u]));               \
             s_[u] = (j_ < pos && MB_[u] != 0) ? d_ * sl2 : -INFINITY;                                                \
             mb_ = fmaxf(mb_, s_[u]);                                                                                 \
         }                                                                                                            \
@@ -425,13 +478,14 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         const float al_ = __builtin_amdgcn_exp2f(m_run - mu_);                                                       \
         m_run = mn_;                                                                                                 \
         float ps_ = 0.f;                                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] *= al_;                                                   \
+        _Pragma("unroll") for (int e = 0; e < E; ++e) o[e] *= al_;                                                   \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
             const float p_ = __builtin_amdgcn_exp2f(s_[u] - mu_);                                                    \
             ps_ += p_;                                                                                               \
-            float vv_[8];                                                                                            \
-            bf8_to_f32(make_uint4(VB_[u].x, VB_[u].y, VB_[u].z, VB_[u].w), vv_);                                     \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, vv_[e], o[e]);                   \
+            float vv_[E];                                                                                            \
+            if constexpr (KV8) fp8x16_to_f32(VB_[u], vv_);                                                           \
+            else bf8_to_f32(make_uint4(VB_[u].x, VB_[u].y, VB_[u].z, VB_[u].w), vv_);                                \
+            _Pragma("unroll") for (int e = 0; e < E; ++e) o[e] = __builtin_fmaf(p_, vv_[e], o[e]);                   \
         }                                                                                                            \
         l_run = l_run * al_ + ps_;                                                                                   \
     }                                                                                                                \
@@ -449,10 +503,10 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     {   // the new token (key / value still in LDS): every group computes it, only group 0 of the workgroup folds it in
         float d_ = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const uint32_t qq = qpk[c * 4 + e / 2];
-            d_ = __builtin_fmaf(__uint_as_float(qq << 16), knew[c * 8 + e], d_);
-            d_ = __builtin_fmaf(__uint_as_float(qq & 0xffff0000u), knew[c * 8 + e + 1], d_);
+        for (int e = 0; e < E; e += 2) {
+            const uint32_t qq = qpk[c * (E / 2) + e / 2];
+            d_ = __builtin_fmaf(__uint_as_float(qq << 16), knew[c * E + e], d_);
+            d_ = __builtin_fmaf(__uint_as_float(qq & 0xffff0000u), knew[c * E + e + 1], d_);
         }
         d_ = group_sum<LPK>(d_);
         const float s_ = (grp == 0 && (!MASK || km[pos] != 0)) ? d_ * sl2 : -INFINITY;
@@ -462,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         m_run = mn_;
         l_run = l_run * al_ + p_;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, vnew[c * 8 + e], o[e] * al_);
+        for (int e = 0; e < E; ++e) o[e] = __builtin_fmaf(p_, vnew[c * E + e], o[e] * al_);
     }
     // ---- merge the KPW lane groups of the wave (butterfly over lanes LPK, 2 LPK, ... apart), then the waves through LDS
 #pragma unroll
@@ -473,17 +527,17 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         const float a1 = __builtin_amdgcn_exp2f(m_run - mu_), a2 = __builtin_amdgcn_exp2f(m2 - mu_);
         l_run = l_run * a1 + l2 * a2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] * a1 + __shfl_xor(o[e], off, 64) * a2;
+        for (int e = 0; e < E; ++e) o[e] = o[e] * a1 + __shfl_xor(o[e], off, 64) * a2;
         m_run = mn_;
     }
     if (lane < LPK) {
         float* pw = part + wave * (D + 2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pw[lane * 8 + e] = o[e];
+        for (int e = 0; e < E; ++e) pw[lane * E + e] = o[e];
         if (lane == 0) { pw[D] = m_run; pw[D + 1] = l_run; }
     }
     __syncthreads();
-    if (tid < LPK) {       // D/8 threads, 8 output dims each
+    if (tid < D / 8) {     // D/8 threads, 8 output dims each
         float mf = part[D];
 #pragma unroll
         for (int w = 1; w < NW; ++w) mf = fmaxf(mf, part[w * (D + 2) + D]);
@@ -512,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
 template <typename T, int D>
 static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_tab, const float* sin_tab, void* out, int B,
                          int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
-                         float scale, int out_frag, hipStream_t s) {
+                         float scale, int out_frag, hipStream_t s, bool kv8 = false) {
     const int sc_cap = (ctx_max + 63) & ~63;
     // batch form: 2-wave workgroups (8 per CU: one round for B * H <= 2048) while the context is short enough that the extra
     // passes over K and V (64 instead of 128 rows per pass) cost less than the second round of workgroups saves
@@ -527,16 +581,28 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
         // bf16: the single-pass kernel (VCLA_ATTN_FLASH=0 restores the phased kernel below for A/B runs).  2-wave workgroups once
         // B * H fills the chip that way (16 per CU by waves), 4 waves otherwise; the row-major output needs 16-byte rows.
         static const int flash_env = getenv("VCLA_ATTN_FLASH") ? atoi(getenv("VCLA_ATTN_FLASH")) : 1;
-        if (flash_env && (out_frag || (((int64_t)H * D) % 8 == 0 && vcla_aligned(out, 16)))) {
-            const bool small_wg = (int64_t)B * H >= 1024 && nw_env != 4;
-#define FD_GO(NW_, MASK_) attn_decode_flash_kernel<D, NW_, MASK_><<<grid, NW_ * 64, 0, s>>>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_tab, sin_tab, \
+        const bool flash_ok = out_frag || (((int64_t)H * D) % 8 == 0 && vcla_aligned(out, 16));
+        const bool small_wg = (int64_t)B * H >= 1024 && nw_env != 4;
+#define FD_GO(NW_, MASK_, KV8_) attn_decode_flash_kernel<D, NW_, MASK_, KV8_><<<grid, NW_ * 64, 0, s>>>((const bf16_t*)qkv, kc, vc, cos_tab, sin_tab, \
                                                     (bf16_t*)out, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag_mt)
-            if (small_wg) { if (key_mask) FD_GO(2, true); else FD_GO(2, false); }
-            else { if (key_mask) FD_GO(4, true); else FD_GO(4, false); }
-#undef FD_GO
+        if (kv8) {   // e4m3 cache rows: the single-pass kernel is the only reader
+            if constexpr (D >= 64) {
+                VCLA_REQUIRE(flash_ok, VCLA_ERR_BAD_ARG, "attn_decode: the fp8 cache needs a 16-byte aligned output with H * d %% 8 == 0");
+                if (small_wg) { if (key_mask) FD_GO(2, true, true); else FD_GO(2, false, true); }
+                else { if (key_mask) FD_GO(4, true, true); else FD_GO(4, false, true); }
+                VCLA_CHECK_LAUNCH("attn_decode_flash_kernel<fp8 cache>");
+                return VCLA_OK;
+            } else {
+                return vcla_fail(VCLA_ERR_BAD_SHAPE, "attn_decode: the fp8 cache needs head dim 64 or 128 (got %d)", D);
+            }
+        }
+        if (flash_env && flash_ok) {
+            if (small_wg) { if (key_mask) FD_GO(2, true, false); else FD_GO(2, false, false); }
+            else { if (key_mask) FD_GO(4, true, false); else FD_GO(4, false, false); }
             VCLA_CHECK_LAUNCH("attn_decode_flash_kernel");
             return VCLA_OK;
         }
+#undef FD_GO
     }
     static const int coop_env = getenv("VCLA_ATTN_COOP") ? atoi(getenv("VCLA_ATTN_COOP")) : -1;   // -1 auto, 0 / 1 force (A/B runs)
     const bool coop = coop_env >= 0 ? coop_env != 0 : (int64_t)B * H >= 512;
@@ -557,7 +623,10 @@ extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_ca
                                       const float* sin_tab, void* out, int B, int H, int d, int ctx_max, int pos0,
                                       const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
                                       int dtype, int out_frag, void* stream) {
+    const bool kv8 = (dtype & VCLA_KV_FP8) != 0;
+    dtype &= ~VCLA_KV_FP8;
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode: bad dtype %d", dtype);
+    VCLA_REQUIRE(!kv8 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode: VCLA_KV_FP8 goes with VCLA_BF16 activations only");
     VCLA_REQUIRE(d == 32 || d == 64 || d == 128, VCLA_ERR_BAD_SHAPE, "attn_decode: head dim %d not in {32,64,128}", d);
     VCLA_REQUIRE(B >= 0 && H > 0 && ctx_max > 0 && pos0 >= 0 && (pos_dev || pos0 < ctx_max), VCLA_ERR_BAD_SHAPE,
                  "attn_decode: B=%d H=%d ctx_max=%d pos0=%d", B, H, ctx_max, pos0);
@@ -568,7 +637,7 @@ extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_ca
                  "attn_decode: out_frag needs bf16, B <= 64 (got %d) and H*d %% 32 == 0", B);
     if (B == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
-#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag, s)
+#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag, s, kv8)
     if (dtype == VCLA_F32) {
         if (d == 32) DEC_CASE(float, 32);
         if (d == 64) DEC_CASE(float, 64);

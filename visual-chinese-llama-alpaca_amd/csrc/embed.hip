@@ -87,8 +87,10 @@ extern "C" int vcla_embed_splice(const int64_t* ids, const void* table, const vo
 // qkv row r = b*T + t : [ q (H*d) | k (H*d) | v (H*d) ].  One workgroup per row; thread handles (h, i<d/2) pairs.
 // q' = q*cos + rot(q)*sin with rot(x) = cat(-x[d/2:], x[:d/2]); cos/sin are rounded to the activation dtype
 // first (HF casts the fp32 tables to x.dtype, hf:llama/modeling_llama.py:127).
-template <typename T>
-__global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+// KV8 (bf16 activations): the cache holds OCP e4m3 bytes (unit scale); the rotated k is also written back into the qkv buffer so that
+// the prefill's own attention reads exact bf16 rows (vcla_model_cfg.t_kv_fp8).
+template <typename T, bool KV8 = false>
+__global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, void* __restrict__ kc_, void* __restrict__ vc_,
                                                       const float* __restrict__ cos_tab,
                                                       const float* __restrict__ sin_tab, int T_, int H, int d,
                                                       int ctx_max, int pos0, const int32_t* __restrict__ pos_dev) {
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __
     T* q = qkv + row * 3 * HD;
     T* k = q + HD;
     const T* v = k + HD;
+    T* kc = (T*)kc_;
+    T* vc = (T*)vc_;
+    unsigned char* kc8 = (unsigned char*)kc_;
+    unsigned char* vc8 = (unsigned char*)vc_;
     const float* cs = cos_tab + (int64_t)pos * half;
     const float* sn = sin_tab + (int64_t)pos * half;
     for (int idx = threadIdx.x; idx < H * half; idx += 256) {
@@ -110,20 +116,40 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __
         Act<T>::st(q + o, q0 * c - q1 * s);
         Act<T>::st(q + o + half, q1 * c + q0 * s);
         const float k0 = Act<T>::ld(k + o), k1 = Act<T>::ld(k + o + half);
-        T* kd = kc + (((int64_t)b * H + h) * ctx_max + pos) * d + i;
-        Act<T>::st(kd, k0 * c - k1 * s);
-        Act<T>::st(kd + half, k1 * c + k0 * s);
+        const int64_t ko = (((int64_t)b * H + h) * ctx_max + pos) * d + i;
+        if constexpr (KV8) {
+            const float r0 = Act<T>::rnd(k0 * c - k1 * s), r1 = Act<T>::rnd(k1 * c + k0 * s);
+            Act<T>::st(k + o, r0);
+            Act<T>::st(k + o + half, r1);
+            const unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, 0, false);
+            kc8[ko] = (unsigned char)(pk & 0xff);
+            kc8[ko + half] = (unsigned char)((pk >> 8) & 0xff);
+        } else {
+            Act<T>::st(kc + ko, k0 * c - k1 * s);
+            Act<T>::st(kc + ko + half, k1 * c + k0 * s);
+        }
     }
-    for (int idx = threadIdx.x; idx < HD; idx += 256) {
-        const int h = idx / d, i = idx % d;
-        vc[(((int64_t)b * H + h) * ctx_max + pos) * d + i] = v[idx];
+    if constexpr (KV8) {
+        for (int idx = threadIdx.x * 2; idx < HD; idx += 512) {     // two adjacent values per thread: one 2-byte store (d is even)
+            const int h = idx / d, i = idx % d;
+            const unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(Act<T>::ld(v + idx), Act<T>::ld(v + idx + 1), 0, false);
+            *reinterpret_cast<unsigned short*>(vc8 + (((int64_t)b * H + h) * ctx_max + pos) * d + i) = (unsigned short)(pk & 0xffff);
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < HD; idx += 256) {
+            const int h = idx / d, i = idx % d;
+            vc[(((int64_t)b * H + h) * ctx_max + pos) * d + i] = v[idx];
+        }
     }
 }
 
 extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
                                    const float* sin_tab, int B, int T, int H, int d, int ctx_max, int pos0,
                                    const int32_t* pos_dev, int dtype, void* stream) {
+    const bool kv8 = (dtype & VCLA_KV_FP8) != 0;
+    dtype &= ~VCLA_KV_FP8;
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "rope_kv_append: bad dtype %d", dtype);
+    VCLA_REQUIRE(!kv8 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "rope_kv_append: VCLA_KV_FP8 goes with VCLA_BF16 activations only");
     VCLA_REQUIRE(B >= 0 && T >= 0 && H > 0 && d > 0 && d % 2 == 0 && ctx_max > 0 && pos0 >= 0, VCLA_ERR_BAD_SHAPE,
                  "rope_kv_append: B=%d T=%d H=%d d=%d ctx_max=%d pos0=%d", B, T, H, d, ctx_max, pos0);
     VCLA_REQUIRE(pos_dev || pos0 + T <= ctx_max, VCLA_ERR_BAD_SHAPE, "rope_kv_append: pos0 %d + T %d > ctx_max %d",
@@ -133,10 +159,12 @@ extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, cons
     if (rows == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VCLA_F32)
-        rope_kv_kernel<float><<<(unsigned)rows, 256, 0, s>>>((float*)qkv, (float*)k_cache, (float*)v_cache, cos_tab,
+        rope_kv_kernel<float><<<(unsigned)rows, 256, 0, s>>>((float*)qkv, k_cache, v_cache, cos_tab,
                                                              sin_tab, T, H, d, ctx_max, pos0, pos_dev);
+    else if (kv8)
+        rope_kv_kernel<bf16_t, true><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache, cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
     else
-        rope_kv_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, (bf16_t*)k_cache, (bf16_t*)v_cache,
+        rope_kv_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache,
                                                               cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
     VCLA_CHECK_LAUNCH("rope_kv_kernel");
     return VCLA_OK;

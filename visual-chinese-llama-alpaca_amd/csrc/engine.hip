@@ -179,6 +179,8 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
                      c.t_hidden % 64 == 0 && c.t_inter % 64 == 0, VCLA_ERR_BAD_SHAPE,
                  "ctx_create: hidden / intermediate sizes must be multiples of 64");
     VCLA_REQUIRE(c.t_inter % 16 == 0, VCLA_ERR_BAD_SHAPE, "ctx_create: t_inter must be a multiple of 16 (SwiGLU packing)");
+    VCLA_REQUIRE(!c.t_kv_fp8 || (c.act_dtype == VCLA_BF16 && c.t_heads > 0 && c.t_hidden / c.t_heads >= 64), VCLA_ERR_BAD_ARG,
+                 "ctx_create: t_kv_fp8 (e4m3 K/V cache) needs bf16 activations and a text head dim of 64 or 128");
     VCLA_REQUIRE(c.r_hidden == c.v_hidden, VCLA_ERR_BAD_SHAPE,
                  "ctx_create: resampler hidden (%d) must equal vision hidden (%d): latents are concatenated with image tokens",
                  c.r_hidden, c.v_hidden);
@@ -432,7 +434,7 @@ extern "C" size_t vcla_llama_workspace_bytes(const vcla_ctx* ctx, int B, int T) 
 }
 extern "C" size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max) {
     if (!ctx || B <= 0 || ctx_max <= 0) return 0;
-    return (size_t)ctx->c.t_layers * 2 * B * ctx->c.t_hidden * (size_t)ctx_max * esz(ctx);
+    return (size_t)ctx->c.t_layers * 2 * B * ctx->c.t_hidden * (size_t)ctx_max * (ctx->c.t_kv_fp8 ? 1 : esz(ctx));   // t_kv_fp8: e4m3 bytes
 }
 
 // ------------------------------------------------------------------ small wrappers
@@ -640,7 +642,9 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     const int dt = c.act_dtype;
     const size_t e = esz(ctx);
     const int D = c.t_hidden, H = c.t_heads, d = D / H, M = B * T;
-    const size_t per = (size_t)B * H * ctx_max * d * e;  // bytes of one K (or V) slab of one layer
+    const bool kv8 = c.t_kv_fp8 != 0;                   // e4m3 cache rows (bf16 activations; checked at ctx creation)
+    const int dkv = dt | (kv8 ? VCLA_KV_FP8 : 0);
+    const size_t per = (size_t)B * H * ctx_max * d * (kv8 ? 1 : e);  // bytes of one K (or V) slab of one layer
     char* kc = (char*)kv_cache + (size_t)(2 * l) * per;
     char* vc = kc + per;
     // 2 <= M <= 64 decode rows with fragment-major weight copies: the streaming GEMMs (gemm_stream.hip).  Every operand is
@@ -669,7 +673,7 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
                     defer && h_ready ? w.ssq : nullptr, defer && h_ready ? ctx->run.ssq_parts : 0));
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
-                                   scale_, dt, /*out_frag=*/1, s));
+                                   scale_, dkv, /*out_frag=*/1, s));
         if (defer) {
             RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq, sk_o));
             RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, ctx->run.ssq_parts));
@@ -698,13 +702,20 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
     if (T == 1) {
         // decode: RoPE + KV append + attention over the cache in one launch
         RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask,
-                                   ctx_max, scale, dt, 0, s));
+                                   ctx_max, scale, dkv, 0, s));
     } else {
-        RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dt, s));
+        VCLA_REQUIRE(!kv8 || (pos0 == 0 && !pos_dev), VCLA_ERR_BAD_ARG,
+                     "llama: with the fp8 K/V cache a multi-token forward must start at position 0 (it attends over its own bf16 rows; "
+                     "the 1-byte cache serves single-token steps)");
+        RUN(vcla_rope_kv_append(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, B, T, H, d, ctx_max, pos0, pos_dev, dkv, s));
         vcla_attn_args a{};
         a.q = w.qkv; a.k = kc; a.v = vc; a.o = w.ao;
         a.q_bs = (int64_t)T * 3 * D; a.q_hs = d; a.q_rs = 3 * D;
         a.k_bs = a.v_bs = (int64_t)H * ctx_max * d; a.k_hs = a.v_hs = (int64_t)ctx_max * d; a.k_rs = a.v_rs = d;
+        if (kv8) {   // keys / values of this very forward, exact bf16, straight from the qkv rows (k was rotated in place)
+            a.k = (const char*)w.qkv + (size_t)D * e; a.v = (const char*)w.qkv + (size_t)2 * D * e;
+            a.k_bs = a.v_bs = a.q_bs; a.k_hs = a.v_hs = d; a.k_rs = a.v_rs = 3 * D;
+        }
         a.o_bs = (int64_t)T * D; a.o_hs = d; a.o_rs = D;
         a.B = B; a.H = H; a.Tq = T; a.D = d; a.scale = scale; a.causal = 1;
         a.key_mask = key_mask; a.key_mask_ld = ctx_max;

@@ -74,6 +74,7 @@ class ModelCfg(C.Structure):
         ("t_hidden", C.c_int), ("t_layers", C.c_int), ("t_heads", C.c_int), ("t_inter", C.c_int),
         ("t_vocab", C.c_int), ("t_max_pos", C.c_int), ("t_eps", C.c_float), ("t_rope_theta", C.c_float),
         ("t_fp8_mfma", C.c_int),
+        ("t_kv_fp8", C.c_int),
     ]
 
 

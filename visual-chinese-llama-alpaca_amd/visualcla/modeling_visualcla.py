@@ -101,6 +101,7 @@ class VisualCLAModel:
         c.t_eps = t.get("rms_norm_eps", 1e-6)
         c.t_rope_theta = float(t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or 10000.0)
         c.t_fp8_mfma = int(bool(getattr(self, "_fp8_mfma", False)) and self._dtype == torch.bfloat16)
+        c.t_kv_fp8 = int(bool(getattr(self, "_kv_fp8", False)) and self._dtype == torch.bfloat16)
         if v.get("hidden_act", "quick_gelu") != "quick_gelu" or r.get("hidden_act", "gelu") != "gelu":
             raise ValueError("only quick_gelu (CLIP) and gelu (resampler) activations are implemented")
         return c
@@ -311,30 +312,34 @@ class VisualCLAModel:
                         self._build_ctx()
         return self
 
-    def enable_fp8_decode(self, enabled: bool = True, prefill: bool = True):
+    def enable_fp8_decode(self, enabled: bool = True, prefill: bool = True, kv_cache: bool = False):
         """BASELINE configs[4] weight path: OCP fp8 (e4m3fn, per-row scale) copies of the LLaMA projection / lm_head
         matrices.  The HBM-bound decode kernels (M <= 128) stream them (half the bytes, dequantised in registers); with
         `prefill` (default) the prefill GEMMs (M > 128) run fp8 x fp8 on the fp8 MFMA pipe
-        (v_mfma_scale_f32_16x16x128_f8f6f4), activations quantised per row on the fly.  The vision stack stays bf16.  The
-        MI355X analogue of the reference's `load_in_8bit` (bitsandbytes on the LLaMA only, modeling_visualcla.py:155)."""
+        (v_mfma_scale_f32_16x16x128_f8f6f4), activations quantised per row on the fly.  `kv_cache=True` also stores the K / V cache
+        as e4m3 bytes (unit scale; at B = 64 the bf16 cache is as many bytes per decode step as the fp8 weights): the prompt's own
+        attention still runs on exact bf16 rows, the decode steps read the 1-byte cache; a multi-token forward onto an existing
+        cache is refused in that mode.  The vision stack stays bf16.  The MI355X analogue of the reference's `load_in_8bit`
+        (bitsandbytes on the LLaMA only, modeling_visualcla.py:155)."""
         if self._dtype != torch.bfloat16:
             raise ValueError("fp8 decode weights need the bf16 activation mode")
         has = any(k.endswith(".q8") for k in self._packed)
         want_mfma = bool(enabled and prefill)
-        if bool(getattr(self, "_fp8_mfma", False)) != want_mfma:
-            self._fp8_mfma = want_mfma
+        want_kv = bool(enabled and kv_cache)
+        rebuild = False
+        if bool(getattr(self, "_fp8_mfma", False)) != want_mfma or bool(getattr(self, "_kv_fp8", False)) != want_kv:
+            self._fp8_mfma, self._kv_fp8 = want_mfma, want_kv
             self._ws.clear()
-            if enabled == has:              # only the MFMA switch changed
-                self._build_ctx()
-                return self
+            rebuild = True
         if enabled and not has:
             add_fp8_copies(self._packed)
+            rebuild = True
         elif not enabled and has:
             for k in [k for k in self._packed if k.endswith((".q8", ".q8f", ".s8"))]:
                 del self._packed[k]
-        else:
-            return self
-        self._build_ctx()
+            rebuild = True
+        if rebuild:
+            self._build_ctx()
         return self
 
     @property
@@ -507,7 +512,8 @@ class VisualCLAModel:
         H, d = t["num_attention_heads"], t["hidden_size"] // t["num_attention_heads"]
         shape = (t["num_hidden_layers"], 2, B, H, ctx_max, d)
         # generate()'s own cache lives in a persistent buffer (never handed to the caller); forward(use_cache=True) returns a fresh one
-        kv = self._typed_buf("gen_kv", shape, self._dtype) if _persistent else torch.empty(*shape, dtype=self._dtype, device=self._device)
+        kdt = torch.uint8 if getattr(self, "_kv_fp8", False) else self._dtype      # e4m3 bytes (enable_fp8_decode(kv_cache=True))
+        kv = self._typed_buf("gen_kv", shape, kdt) if _persistent else torch.empty(*shape, dtype=kdt, device=self._device)
         return VclaCache(kv, 0, ctx_max)
 
     def _key_mask(self, attention_mask: Optional[torch.Tensor], B: int, T: int, ctx_max: int, extra: int):
