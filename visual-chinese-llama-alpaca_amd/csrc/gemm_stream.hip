@@ -204,7 +204,11 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
 #pragma unroll
                     for (int tt = 0; tt < TPU; ++tt) { sum[0][tt][0] *= rs; sum[0][tt][1] *= rs; sum[0][tt][2] *= rs; sum[0][tt][3] *= rs; }
                 }
-                gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, c.lane);
+                // the lane id is laundered: everything the epilogue derives from it (column quads, fragment offsets) is recomputed HERE instead
+                // of being computed at kernel entry and carried -- spilled to scratch, in the M = 64 SwiGLU instance -- across the K loop
+                int ln = c.lane;
+                asm volatile("" : "+v"(ln));
+                gemm_epilogue<EPI, OutT, 1, TPU>(a, sum, i * 16, (c0 + jj * TPU) * 16, ln);
             }
         }
         __syncthreads();
