@@ -212,7 +212,7 @@ def vit_gemm_roofline(model, B: int = 64, n_rep: int = 20):
     sec = _event_time(run, n_rep) / L
     flops = 2.0 * M * I * D
     tf = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_mfma256_kernel<QUICK_GELU> (ViT fc1, M={M} N={I} K={D}, + its ragged-M tail launch)",
+    return {"bound": "mfma", "kernel": f"gemm_mfma256_kernel<QUICK_GELU> (ViT fc1, M={M} N={I} K={D}; one launch of 257-row tiles, L2-prefetch form)",
             "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
             "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
 
