@@ -138,7 +138,9 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         int prow = wave == 0 ? n0 + 64 * (tm & 3) + lane : m0 + 32 * (tn & 7) + (lane & 31);
         if (wave == 0) prow = prow < n_pad ? prow : n_pad - 1; else prow = prow < a.M ? prow : a.M - 1;
         const bf16_t* pfsrc = wave == 0 ? Wg + (int64_t)prow * a.K : Ag + (int64_t)prow * a.lda;
-        const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 2 * STAGE + (wave & 1) * 256);
+        // (every workgroup touching ALL 512 lines of its own slab -- one touch per wave and K step -- is slower: B = 64 prefill 98.1 vs 92.5 ms,
+        // profiles/r03_gemm256_ab.txt run 25: the touches are not free, sharing them across the workgroups of a panel is what pays)
+        const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 2 * STAGE + (wave & 1) * 256);   // (sink bytes are never read: waves may share them)
         auto touch = [&](int kt) {
             if (pf_wave) g2_dma4(pfsrc + (int64_t)(kt < nk ? kt : nk - 1) * GM_BK, sink);
         };
