@@ -182,6 +182,10 @@ typedef struct vcla_gemm_args {
        second, fully parallel launch sums the slices in order and applies the epilogue (bias, residual, C, C_frag, c_row_ssq).
        Epilogue NONE only. */
     int ds_splitk;
+    /* with ds_splitk > 1: 1 = stop after the first launch -- splitk_ws then holds the RAW fp32 slices [ds_splitk][M][N] (no rstd of
+       a_row_ssq, no fp8 weight scale, no bias applied; C / C_frag / c_row_ssq untouched) for a consumer that sums them itself
+       (vcla_attn_decode_fused_parts: the qkv projection of a batch decode step).  a_row_ssq may be set (it is not applied). */
+    int ds_raw_partials;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */
@@ -266,6 +270,16 @@ int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* co
 int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab,
                            void* out, int B, int H, int d, int ctx_max, int pos0, const int32_t* pos_dev,
                            const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, int out_frag, void* stream);
+
+/* The same step when the qkv projection ran as TWO K slices that were not reduced (vcla_gemm_args.ds_raw_partials): qkv_parts = slice 0,
+   fp32 [B][3*H*d], slice 1 slice_stride elements behind it.  The kernel sums the slices and applies what the GEMM epilogue would have:
+   row_ssq (optional, [B][16] partial sums of squares of the un-normalised row: rstd = rsqrt(sum / (H*d) + norm_eps), the deferred RMSNorm)
+   and w_scale (optional, [3*H*d] fp8 weight scales), rounds to bf16 and proceeds as vcla_attn_decode_fused.  bf16 (| VCLA_KV_FP8), head dim
+   64 / 128, B * H >= 1024 (the 2-wave batch form).  Saves the reduce launch AND half of every CU's activation reads in the qkv GEMM. */
+int vcla_attn_decode_fused_parts(const float* qkv_parts, int64_t slice_stride, const float* row_ssq, const float* w_scale, float norm_eps,
+                                 void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab, void* out, int B, int H, int d,
+                                 int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
+                                 int dtype, int out_frag, void* stream);
 
 /* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
 int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);

@@ -17,6 +17,7 @@ SETTINGS = [
     {"VCLA_DS_DEFER": "0"},                 # a norm launch per RMSNorm instead of the deferred form
     {"VCLA_DS_SPLITK": "2"},
     {"VCLA_DS_GRID": "128"},
+    {"VCLA_DS_QKV_SPLIT": "0"},             # qkv unsplit + plain decode attention instead of two raw K slices summed by the attention kernel
     {"VCLA_GEMV1X": "0"},                   # runtime-K decode GEMV
     {"VCLA_GEMV_OCC": "1"},
     {"VCLA_ATTN_FLASH": "0"},               # the phased decode attention of round 2

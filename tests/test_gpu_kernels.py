@@ -505,6 +505,91 @@ def test_attn_decode_fused_fp8_cache(lib, B, H, d, pos, frag):
                                            ctx, pos, None, None, 0, 1 / math.sqrt(d), lib.dtype_code(torch.float32) | KV_FP8, 0, lib.stream_ptr()))
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,N,K", [(64, 12288, 4096), (48, 1536, 1024), (64, 4096, 2048), (33, 1000, 1408)])
+def test_gemm_dstream_raw_partials(lib, M, N, K, fp8):
+    """ds_raw_partials: split-K without the reduce launch -- the workspace holds the RAW fp32 slices [S][M][N] (no bias, no fp8 scale, no rstd)
+    for a consumer that sums them (the decode attention).  (64, 12288, 4096) = the LLaMA qkv shape: 6 tiles per pair of workgroups, the wide
+    kernel; the others fall back to the 4-tile kernel."""
+    from visualcla.weights import to_fragment_major, quantize_fp8_rows, to_fragment_pair_major_fp8
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    wp = _pack(w)
+    kw = dict(w_frag=to_fragment_major(wp))
+    scale = None
+    wref = w
+    if fp8:
+        q, sc = quantize_fp8_rows(wp)
+        wref = q[:N].view(torch.float8_e4m3fn).float().cpu()      # the raw slices are in units of the fp8 codes
+        scale = sc[:N].float().cpu()
+        kw = dict(w_q8_frag=to_fragment_pair_major_fp8(q), w_scale=sc)
+    af = lib.to_frag(a.to(DEV, torch.bfloat16))
+    ws = torch.full((32 << 18,), float("nan"), dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    ssq_in = torch.ones(M, 16, dtype=torch.float32, device=DEV)          # accepted and NOT applied
+    lib.gemm(None, wp, N, out=out, force_kernel=9, a_frag=af, m=M, splitk_ws=ws.view(torch.uint8), ds_splitk=2, ds_raw_partials=True, a_row_ssq=ssq_in,
+             a_norm_eps=1e-6, **kw)
+    torch.cuda.synchronize()
+    parts = ws[: 2 * M * N].view(2, M, N).cpu()
+    assert torch.isfinite(parts).all()
+    ref = a @ wref.t()
+    _cmp(f"gemm_dstream_raw_partials[{M}x{N}x{K},fp8={fp8}]", parts.sum(0), ref, atol=(2e-3 if not fp8 else 0.5), rtol=1e-4)
+    assert float((out.float() - 7.0).abs().max()) == 0.0                 # C untouched
+    if scale is not None:
+        assert scale.shape[0] == N
+
+
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("B,H,d,pos,with_norm,with_wscale", [(33, 32, 128, 150, True, False), (64, 32, 128, 191, True, True), (40, 32, 64, 5, False, False)])
+def test_attn_decode_fused_parts(lib, B, H, d, pos, with_norm, with_wscale, kv8):
+    """vcla_attn_decode_fused_parts: q / k / v arrive as TWO raw fp32 K slices of the qkv projection (+ the row's 16 partial sums of squares
+    for the deferred RMSNorm, + fp8 weight scales); the kernel must do exactly what reduce launch + vcla_attn_decode_fused do: same output
+    bits, same appended cache rows"""
+    from visualcla.weights import rope_tables
+    ctx = (pos + 64) // 64 * 64
+    g = torch.Generator().manual_seed(B + H + d + pos)
+    HD = H * d
+    p0 = torch.randn(B, 3 * HD, generator=g) * 2
+    p1 = torch.randn(B, 3 * HD, generator=g) * 2
+    ssq = torch.rand(B, 16, generator=g) * 300 + 10 if with_norm else None
+    wsc = (torch.rand(3 * HD, generator=g) * 0.5 + 0.75) if with_wscale else None
+    eps = 1e-6
+    parts = torch.stack([p0, p1]).to(DEV).contiguous()
+    qkv_d = parts[0] + parts[1]                   # the same fp32 arithmetic as the kernel, on the device
+    if with_norm:
+        qkv_d = qkv_d * torch.rsqrt(ssq.to(DEV).sum(1, keepdim=True) / HD + eps)
+    if with_wscale:
+        qkv_d = qkv_d * wsc.to(DEV)
+    qkv_bf = qkv_d.to(torch.bfloat16).contiguous()
+    mk = (lambda: torch.randn(B, H, ctx, d, generator=g).to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)) if kv8 else (lambda: torch.randn(B, H, ctx, d, generator=g).to(DEV, torch.bfloat16))
+    kc, vc = mk(), mk()
+    kc2, vc2 = kc.clone(), vc.clone()
+    cos, sin = rope_tables(1024, d, 10000.0)
+    cos_d, sin_d = cos.to(DEV), sin.to(DEV)
+    km = torch.ones(B, ctx, dtype=torch.int32, device=DEV)
+    km[0, 1:3] = 0
+    dt = lib.dtype_code(torch.bfloat16) | (KV_FP8 if kv8 else 0)
+    MT = (B + 15) // 16
+    out_a = torch.zeros(HD // 32, MT, 64, 8, dtype=torch.bfloat16, device=DEV)
+    out_b = torch.zeros_like(out_a)
+    L = lib.load()
+    ssq_d = ssq.to(DEV).contiguous() if with_norm else None
+    wsc_d = wsc.to(DEV).contiguous() if with_wscale else None
+    lib.check(L.vcla_attn_decode_fused(qkv_bf.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(), out_a.data_ptr(), B, H, d, ctx, pos,
+                                       None, km.data_ptr(), ctx, 1 / math.sqrt(d), dt, 1, lib.stream_ptr()))
+    lib.check(L.vcla_attn_decode_fused_parts(parts.data_ptr(), B * 3 * HD, lib.ptr(ssq_d), lib.ptr(wsc_d), eps, kc2.data_ptr(), vc2.data_ptr(), cos_d.data_ptr(),
+                                             sin_d.data_ptr(), out_b.data_ptr(), B, H, d, ctx, pos, None, km.data_ptr(), ctx, 1 / math.sqrt(d), dt, 1, lib.stream_ptr()))
+    torch.cuda.synchronize()
+    # the device's own fp32 product (parts sum * rstd * scale) may differ from the kernel's by an ulp before the bf16 rounding: compare with a bf16-step tolerance,
+    # and demand bit equality wherever the rounded inputs agree (checked through the appended cache rows)
+    same_k = torch.equal(kc2[:, :, pos], kc[:, :, pos]) and torch.equal(vc2[:, :, pos], vc[:, :, pos])
+    _cmp(f"attn_decode_parts[B{B}H{H}d{d}pos{pos}kv8={kv8}]", lib.from_frag(out_b, B), lib.from_frag(out_a, B).float(), atol=0.0 if same_k else 2e-2)
+    _cmp("attn_decode_parts.k_append", kc2[:, :, pos].float() if not kv8 else kc2[:, :, pos].view(torch.float8_e4m3fn).float(),
+         kc[:, :, pos].float() if not kv8 else kc[:, :, pos].view(torch.float8_e4m3fn).float(), atol=0.13 if kv8 else 3.2e-2, rtol=0.13 if kv8 else 8e-3)
+    assert torch.equal(kc2[:, :, :pos], kc[:, :, :pos]) and torch.equal(vc2[:, :, pos + 1:], vc[:, :, pos + 1:])
+
+
 def test_rope_kv_append_fp8_cache(lib):
     """prefill side of VCLA_KV_FP8: q and k rotated IN PLACE in the qkv buffer (bf16, what the prompt's own attention reads), the cache
     receives the e4m3 bytes of the rotated k and of v"""

@@ -253,6 +253,11 @@ def main():
                     for w, wf in zip(ws, wfs):
                         _lib.gemm(None, w, N, epilogue=epi, out=out, out_f32=f32, residual=res, force_kernel=9, a_frag=af, m=M, w_frag=wf)
                 t8, t9 = timeit(run8, reps=10) / nb, timeit(run9, reps=10) / nb
+                if tag == "qkv" and M > 32:     # as the engine runs it at M > 32: two K slices, raw fp32 partials (the attention sums them), no reduce launch
+                    def run9r():
+                        for w, wf in zip(ws, wfs):
+                            _lib.gemm(None, w, N, out=out, force_kernel=9, a_frag=af, m=M, w_frag=wf, splitk_ws=skws, ds_splitk=2, ds_raw_partials=True)
+                    print(f"M={M:3d} qkv      k9 split in 2 K slices, raw partials (wide kernel, no reduce launch): {timeit(run9r, reps=10) / nb * 1e6:6.1f} us   (unsplit k9 {t9*1e6:.1f} us)")
                 if res is not None:     # o / down: the split-K form of the streaming kernel (+ its reduce launch), as the engine runs it
                     cfr = torch.zeros(n_out // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV)
                     ssq = torch.zeros(M, n_out // 16, dtype=torch.float32, device=DEV)
@@ -380,7 +385,16 @@ def main():
             out = torch.zeros((H * d) // 32, (B + 15) // 16, 64, 8, dtype=torch.bfloat16, device=DEV) if frag else torch.empty(B, H * d, dtype=torch.bfloat16, device=DEV)
             L = _lib.load()
             for pos in poss:
-                def run():
+                qparts = torch.randn(2, B, 3 * H * d, device=DEV)
+                ssq = torch.rand(B, 16, device=DEV) * 100 + 1
+                if int(os.environ.get("VCLA_BENCH_QP", "0")) and B * H >= 1024:
+                    def run():
+                        for kc, vc in zip(kcs, vcs):
+                            _lib.check(L.vcla_attn_decode_fused_parts(qparts.data_ptr(), B * 3 * H * d, ssq.data_ptr(), None, 1e-6, kc.data_ptr(), vc.data_ptr(), cos.data_ptr(),
+                                                                      sin.data_ptr(), out.data_ptr(), B, H, d, ctx_max, pos, None, None, 0, 1 / math.sqrt(d),
+                                                                      _lib.dtype_code(torch.bfloat16) | (0x100 if kv8 else 0), frag, _lib.stream_ptr()))
+                else:
+                  def run():
                     for kc, vc in zip(kcs, vcs):
                         _lib.check(L.vcla_attn_decode_fused(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
                                                             B, H, d, ctx_max, pos, None, None, 0, 1 / math.sqrt(d), _lib.dtype_code(torch.bfloat16) | (0x100 if kv8 else 0), frag,

@@ -17,7 +17,7 @@ echo "== bench fp8 B=64"; timeout 900 python bench.py --fp8 --batch 64 --steps 2
 echo "== bench fp8 336px B=32 (per-GPU share of configs[4])"; timeout 900 python bench.py --fp8 --image-size 336 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_336px_fp8_b32.json; cut -c1-200 gpurun_out/${tag}_bench_336px_fp8_b32.json
 echo "== bench sampled"; timeout 600 python bench.py --sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_sample.json; cut -c1-200 gpurun_out/${tag}_bench_sample.json
 echo "== bench strong scaling mode, 1 GPU (global batch 256 = 4 x 64 would not fit one step's buffers of the default; 64 here)"; timeout 900 python bench.py --global-batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_strong_gb64.json; cut -c1-200 gpurun_out/${tag}_bench_strong_gb64.json
-for cfg in "b1:--steps 2 --warmup 1 --steps-b64 0 --no-cpu-baseline" "b64:--batch 64 --steps 1 --warmup 1 --no-cpu-baseline"; do
+for cfg in "b1:--steps 2 --warmup 1 --steps-b64 0 --steps-c4 0 --no-cpu-baseline" "b64:--batch 64 --steps 1 --warmup 1 --steps-c4 0 --no-cpu-baseline"; do
   nm=${cfg%%:*}; args=${cfg#*:}
   echo "== rocprofv3 --kernel-trace --stats: bench.py $args"
   rm -rf gpurun_out/prof_$nm

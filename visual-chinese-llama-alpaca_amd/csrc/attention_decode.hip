@@ -359,12 +359,17 @@ __device__ __forceinline__ float fp8_round(float x) {
     return r.x;
 }
 
-template <int D, int NW, bool MASK, bool KV8 = false>
-__global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_kernel(const bf16_t* __restrict__ qkv, void* __restrict__ kc_, void* __restrict__ vc_,
+// QP: the qkv row of the step does not exist yet -- the qkv projection ran split in two K slices and left RAW fp32 partial rows
+// (vcla_gemm_args.ds_raw_partials).  `qkv` is then the first slice (fp32 [B][3 H D]), `qp.slice` the distance to the second; the lanes
+// that read q / k / v sum the slices, apply what the GEMM epilogue would have (the deferred-RMSNorm rstd of the row from its 16 partial
+// sums of squares, the fp8 weight scale of the column) and round to bf16: the values the reduce launch would have stored.
+struct QkvParts { int64_t slice; const float* ssq; const float* w_scale; float inv_hidden, eps; };
+template <int D, int NW, bool MASK, bool KV8 = false, bool QP = false>
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_kernel(const void* __restrict__ qkv_, void* __restrict__ kc_, void* __restrict__ vc_,
                                                                 const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                                 bf16_t* __restrict__ out, int H, int ctx_max, int pos0,
                                                                 const int32_t* __restrict__ pos_dev, const int32_t* __restrict__ key_mask,
-                                                                int64_t key_mask_ld, float scale, int out_frag_mt) {
+                                                                int64_t key_mask_ld, float scale, int out_frag_mt, QkvParts qp = QkvParts{}) {
     // U keys per lane group and batch.  The 2-wave form (batch decode: thousands of workgroups, 4 waves per SIMD) keeps 2 x 4 rows of K
     // and V per lane in flight; the 4-wave form (a few dozen latency-bound workgroups: B = 1) 2 x 8 -- with D = 128 its 16 groups
     // then have the first 256 keys of the context requested before the RoPE phase ends
@@ -385,7 +390,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     const int h = blockIdx.x, b = blockIdx.y;
     const int pos = pos0 + (pos_dev ? *pos_dev : 0);         // position of the new token = number of cached keys
     const int HD = H * D;
-    const bf16_t* row = qkv + (int64_t)b * 3 * HD;
+    const bf16_t* row = (const bf16_t*)qkv_ + (int64_t)b * 3 * HD;
+    const float* prow = (const float*)qkv_ + (int64_t)b * 3 * HD;      // QP: slice 0 of this sequence's row
     unsigned char* kbase = (unsigned char*)kc_ + ((int64_t)b * H + h) * ctx_max * D * ESZ;
     unsigned char* vbase = (unsigned char*)vc_ + ((int64_t)b * H + h) * ctx_max * D * ESZ;
     const int32_t* km = key_mask ? key_mask + b * key_mask_ld : nullptr;
@@ -394,10 +400,27 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
     // ---- RoPE inputs first (small, needed first), the first batch of cache rows right behind them: vmcnt retires in order, so
     // this order lets the RoPE phase run while the rows are still in flight
     float rc = 0.f, rs = 0.f, q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
+    float qp_rstd = 1.f;
+    float pq[2][4];           // QP: the two slices of (q0, q1, k0, k1)
+    if constexpr (QP) {
+        // rstd of the row (deferred RMSNorm): 16 partial sums of squares, one per lane of every 16-lane row of the wave
+        float ss = qp.ssq ? qp.ssq[(int64_t)b * 16 + (lane & 15)] : 0.f;
+        ss = group_sum<16>(ss);
+        qp_rstd = qp.ssq ? rsqrtf(ss * qp.inv_hidden + qp.eps) : 1.f;
+    }
     if (tid < HALF) {
         rc = cos_tab[(int64_t)pos * HALF + tid]; rs = sin_tab[(int64_t)pos * HALF + tid];
-        q0 = bf2f(row[h * D + tid]); q1 = bf2f(row[h * D + tid + HALF]);
-        k0 = bf2f(row[HD + h * D + tid]); k1 = bf2f(row[HD + h * D + tid + HALF]);
+        if constexpr (QP) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const float* pr = prow + sl * qp.slice;
+                pq[sl][0] = pr[h * D + tid]; pq[sl][1] = pr[h * D + tid + HALF];
+                pq[sl][2] = pr[HD + h * D + tid]; pq[sl][3] = pr[HD + h * D + tid + HALF];
+            }
+        } else {
+            q0 = bf2f(row[h * D + tid]); q1 = bf2f(row[h * D + tid + HALF]);
+            k0 = bf2f(row[HD + h * D + tid]); k1 = bf2f(row[HD + h * D + tid + HALF]);
+        }
     }
     u32x4_t kA[U], vA[U], kB[U], vB[U];
     int mA[U], mB[U];
@@ -423,6 +446,14 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         FD_LOAD(kA, vA, mA, 0)
         FD_LOAD(kB, vB, mB, 1)
     }
+    if constexpr (QP) {
+        if (tid < HALF) {     // what the GEMM epilogue + reduce would have stored: (slice 0 + slice 1) * rstd * w_scale, rounded to bf16
+            const float w0 = qp.w_scale ? qp.w_scale[h * D + tid] : 1.f, w1 = qp.w_scale ? qp.w_scale[h * D + tid + HALF] : 1.f;
+            const float w2 = qp.w_scale ? qp.w_scale[HD + h * D + tid] : 1.f, w3 = qp.w_scale ? qp.w_scale[HD + h * D + tid + HALF] : 1.f;
+            q0 = Act<bf16_t>::rnd((pq[0][0] + pq[1][0]) * qp_rstd * w0); q1 = Act<bf16_t>::rnd((pq[0][1] + pq[1][1]) * qp_rstd * w1);
+            k0 = Act<bf16_t>::rnd((pq[0][2] + pq[1][2]) * qp_rstd * w2); k1 = Act<bf16_t>::rnd((pq[0][3] + pq[1][3]) * qp_rstd * w3);
+        }
+    }
     if (tid < HALF) {
         const float cr = Act<bf16_t>::rnd(rc), sr = Act<bf16_t>::rnd(rs);
         const float a0 = Act<bf16_t>::rnd(q0 * cr - q1 * sr), a1 = Act<bf16_t>::rnd(q1 * cr + q0 * sr);
@@ -440,7 +471,13 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
         }
     } else {
         for (int i = tid - HALF; i < D; i += NT - HALF) {    // the threads past the RoPE lanes move the value row
-            const bf16_t v = row[2 * HD + h * D + i];
+            bf16_t v;
+            if constexpr (QP) {
+                const float ws_ = qp.w_scale ? qp.w_scale[2 * HD + h * D + i] : 1.f;
+                v = f2bf((prow[2 * HD + h * D + i] + prow[qp.slice + 2 * HD + h * D + i]) * qp_rstd * ws_);
+            } else {
+                v = row[2 * HD + h * D + i];
+            }
             if constexpr (KV8) {
                 vnew[i] = fp8_round(bf2f(v));
                 vbase[(int64_t)pos * D + i] = f32_to_fp8(bf2f(v));
@@ -566,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 4 : 2) void attn_decode_flash_ke
 template <typename T, int D>
 static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_tab, const float* sin_tab, void* out, int B,
                          int H, int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld,
-                         float scale, int out_frag, hipStream_t s, bool kv8 = false) {
+                         float scale, int out_frag, hipStream_t s, bool kv8 = false, const QkvParts* qp = nullptr) {
     const int sc_cap = (ctx_max + 63) & ~63;
     // batch form: 2-wave workgroups (8 per CU: one round for B * H <= 2048) while the context is short enough that the extra
     // passes over K and V (64 instead of 128 rows per pass) cost less than the second round of workgroups saves
@@ -583,8 +620,22 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
         static const int flash_env = getenv("VCLA_ATTN_FLASH") ? atoi(getenv("VCLA_ATTN_FLASH")) : 1;
         const bool flash_ok = out_frag || (((int64_t)H * D) % 8 == 0 && vcla_aligned(out, 16));
         const bool small_wg = (int64_t)B * H >= 1024 && nw_env != 4;
-#define FD_GO(NW_, MASK_, KV8_) attn_decode_flash_kernel<D, NW_, MASK_, KV8_><<<grid, NW_ * 64, 0, s>>>((const bf16_t*)qkv, kc, vc, cos_tab, sin_tab, \
+#define FD_GO(NW_, MASK_, KV8_) attn_decode_flash_kernel<D, NW_, MASK_, KV8_><<<grid, NW_ * 64, 0, s>>>(qkv, kc, vc, cos_tab, sin_tab, \
                                                     (bf16_t*)out, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag_mt)
+        if (qp) {    // q / k / v arrive as two raw fp32 K slices of the qkv projection: 2-wave form only (batch decode, B * H >= 1024)
+            if constexpr (D >= 64) {
+                VCLA_REQUIRE(flash_ok && small_wg, VCLA_ERR_BAD_ARG, "attn_decode: the split-qkv form needs B * H >= 1024 and a 16-byte aligned output");
+#define FD_GOP(MASK_, KV8_) attn_decode_flash_kernel<D, 2, MASK_, KV8_, true><<<grid, 128, 0, s>>>(qkv, kc, vc, cos_tab, sin_tab, (bf16_t*)out, H, ctx_max, pos0, pos_dev, \
+                                                                                                 key_mask, key_mask_ld, scale, out_frag_mt, *qp)
+                if (kv8) { if (key_mask) FD_GOP(true, true); else FD_GOP(false, true); }
+                else { if (key_mask) FD_GOP(true, false); else FD_GOP(false, false); }
+#undef FD_GOP
+                VCLA_CHECK_LAUNCH("attn_decode_flash_kernel<split qkv>");
+                return VCLA_OK;
+            } else {
+                return vcla_fail(VCLA_ERR_BAD_SHAPE, "attn_decode: the split-qkv form needs head dim 64 or 128 (got %d)", D);
+            }
+        }
         if (kv8) {   // e4m3 cache rows: the single-pass kernel is the only reader
             if constexpr (D >= 64) {
                 VCLA_REQUIRE(flash_ok, VCLA_ERR_BAD_ARG, "attn_decode: the fp8 cache needs a 16-byte aligned output with H * d %% 8 == 0");
@@ -619,10 +670,34 @@ static int launch_decode(const void* qkv, void* kc, void* vc, const float* cos_t
     return VCLA_OK;
 }
 
+static int attn_decode_entry(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab, void* out, int B, int H, int d,
+                             int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale, int dtype, int out_frag,
+                             void* stream, const QkvParts* qp);
+
+extern "C" int vcla_attn_decode_fused_parts(const float* qkv_parts, int64_t slice_stride, const float* row_ssq, const float* w_scale, float norm_eps,
+                                            void* k_cache, void* v_cache, const float* cos_tab, const float* sin_tab, void* out, int B, int H, int d,
+                                            int ctx_max, int pos0, const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
+                                            int dtype, int out_frag, void* stream) {
+    VCLA_REQUIRE(qkv_parts && slice_stride >= (int64_t)B * 3 * H * d && vcla_aligned(qkv_parts, 16), VCLA_ERR_BAD_ARG,
+                 "attn_decode_parts: qkv_parts = two fp32 slices [B][3 H d], slice_stride elements apart");
+    VCLA_REQUIRE((dtype & ~VCLA_KV_FP8) == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode_parts: bf16 activations only");
+    QkvParts qp{slice_stride, row_ssq, w_scale, 1.0f / (float)(H * d), norm_eps};
+    return attn_decode_entry(qkv_parts, k_cache, v_cache, cos_tab, sin_tab, out, B, H, d, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, dtype, out_frag,
+                             stream, &qp);
+}
+
 extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
                                       const float* sin_tab, void* out, int B, int H, int d, int ctx_max, int pos0,
                                       const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
                                       int dtype, int out_frag, void* stream) {
+    return attn_decode_entry(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, d, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, dtype, out_frag, stream,
+                             nullptr);
+}
+
+static int attn_decode_entry(const void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
+                             const float* sin_tab, void* out, int B, int H, int d, int ctx_max, int pos0,
+                             const int32_t* pos_dev, const int32_t* key_mask, int64_t key_mask_ld, float scale,
+                             int dtype, int out_frag, void* stream, const QkvParts* qp) {
     const bool kv8 = (dtype & VCLA_KV_FP8) != 0;
     dtype &= ~VCLA_KV_FP8;
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "attn_decode: bad dtype %d", dtype);
@@ -637,7 +712,7 @@ extern "C" int vcla_attn_decode_fused(const void* qkv, void* k_cache, void* v_ca
                  "attn_decode: out_frag needs bf16, B <= 64 (got %d) and H*d %% 32 == 0", B);
     if (B == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
-#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag, s, kv8)
+#define DEC_CASE(TT, DD) return launch_decode<TT, DD>(qkv, k_cache, v_cache, cos_tab, sin_tab, out, B, H, ctx_max, pos0, pos_dev, key_mask, key_mask_ld, scale, out_frag, s, kv8, qp)
     if (dtype == VCLA_F32) {
         if (d == 32) DEC_CASE(float, 32);
         if (d == 64) DEC_CASE(float, 64);

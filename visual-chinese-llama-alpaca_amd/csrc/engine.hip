@@ -471,10 +471,11 @@ static int gemm(vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const 
 // streaming decode GEMM (gemm_stream.hip): fragment-major activations in, optional fragment-major copy out
 static int gemm_ds(vcla_ctx* ctx, hipStream_t s, const void* A_frag, const void* W, const WVar& wv, const void* residual, int64_t ldr,
                    void* C, int64_t ldc, void* C_frag, int M, int N, int K, int epi, int out_f32 = 0, const float* a_ssq = nullptr,
-                   int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr, int splitk = 0) {
+                   int a_parts = 0, const float* c_gamma = nullptr, float* c_ssq = nullptr, int splitk = 0, bool raw = false) {
     vcla_gemm_args a{};
     if (splitk > 1 && ctx->run.splitk_ws && (size_t)splitk * M * N * 4 <= SPLITK_WS_BYTES && epi == VCLA_EPI_NONE && !out_f32) {
         a.ds_splitk = splitk; a.splitk_ws = ctx->run.splitk_ws; a.splitk_ws_bytes = SPLITK_WS_BYTES;
+        a.ds_raw_partials = raw ? 1 : 0;
     }
     // partial sums of squares per row this call leaves in c_ssq: the split-K reduce launch writes one per 256 columns (N % 256 ==
     // 0), the in-kernel epilogue one per 16-column tile; the consumer (the next gemm_ds with a_ssq) must be told which
@@ -670,10 +671,27 @@ static int llama_layer(vcla_ctx* ctx, hipStream_t s, const LlamaLayer& L, const 
         const int sk_o = (M > 32 && D >= 2048 && sk_env > 1) ? 2 : 0, sk_d = (M > 16 && c.t_inter >= 4096) ? sk_env : 0;
         const float scale_ = 1.0f / sqrtf((float)d);
         if (!(defer && h_ready)) RUN(vcla_rmsnorm_pack(w.x, D, L.ln1g, w.h, M, D, c.t_eps, s));
-        RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
-                    defer && h_ready ? w.ssq : nullptr, defer && h_ready ? ctx->run.ssq_parts : 0));
-        RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
-                                   scale_, dkv, /*out_frag=*/1, s));
+        // qkv: like o_proj / down_proj it is bound by every CU reading the whole activation panel -- but its consumer reads just ONE row per
+        // workgroup, so the K slices need no reduce launch: the projection leaves two raw fp32 slices (6 tiles per pair of workgroups, one
+        // pass over half of K each) and the attention kernel sums them while it loads q / k / v, applying the deferred-RMSNorm rstd and the
+        // fp8 weight scale itself.  M > 32 (below that the panel is small), B * H >= 1024 (the 2-wave attention form), 16 partial sums per row.
+        static const int qs_env = getenv("VCLA_DS_QKV_SPLIT") ? atoi(getenv("VCLA_DS_QKV_SPLIT")) : 1;
+        const bool a_def = defer && h_ready;
+        const bool qkv_split = qs_env && M > 32 && (int64_t)B * H >= 1024 && d >= 64 && ctx->run.splitk_ws && (size_t)2 * M * 3 * D * 4 <= SPLITK_WS_BYTES &&
+                               (!a_def || ctx->run.ssq_parts == 16);
+        if (qkv_split) {
+            RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
+                        nullptr, 0, nullptr, nullptr, /*splitk=*/2, /*raw=*/true));
+            const bool q8 = ctx->run.decode_step && L.vqkv.q8f && L.vqkv.s8;
+            RUN(vcla_attn_decode_fused_parts((const float*)ctx->run.splitk_ws, (int64_t)M * 3 * D, a_def ? w.ssq : nullptr, q8 ? (const float*)L.vqkv.s8 : nullptr,
+                                             c.t_eps, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
+                                             scale_, dkv, /*out_frag=*/1, s));
+        } else {
+            RUN(gemm_ds(ctx, s, w.h, L.wqkv, L.vqkv, nullptr, 0, w.qkv, 3 * D, nullptr, M, 3 * D, D, VCLA_EPI_NONE, 0,
+                        a_def ? w.ssq : nullptr, a_def ? ctx->run.ssq_parts : 0));
+            RUN(vcla_attn_decode_fused(w.qkv, kc, vc, ctx->rope_cos, ctx->rope_sin, w.ao, B, H, d, ctx_max, pos0, pos_dev, key_mask, ctx_max,
+                                       scale_, dkv, /*out_frag=*/1, s));
+        }
         if (defer) {
             RUN(gemm_ds(ctx, s, w.ao, L.wo, L.vo, w.x, D, w.x, D, w.h, M, D, D, VCLA_EPI_NONE, 0, nullptr, 0, L.ln2g, w.ssq, sk_o));
             RUN(gemm_ds(ctx, s, w.h, L.wgu, L.vgu, nullptr, 0, nullptr, 0, w.act, M, 2 * c.t_inter, D, VCLA_EPI_SWIGLU, 0, w.ssq, ctx->run.ssq_parts));

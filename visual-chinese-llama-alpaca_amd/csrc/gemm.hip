@@ -1294,7 +1294,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(!a->c_row_ssq || (a->epilogue == VCLA_EPI_NONE && !a->out_f32 && a->N % 16 == 0), VCLA_ERR_BAD_ARG,
                      "gemm: c_row_ssq needs epilogue NONE, a bf16 output and N %% 16 == 0");
         VCLA_REQUIRE(!a->a_row_ssq || a->a_row_ssq_parts > 0, VCLA_ERR_BAD_ARG, "gemm: a_row_ssq needs a_row_ssq_parts > 0");
-        VCLA_REQUIRE(!(a->a_row_ssq && a->ds_splitk > 1), VCLA_ERR_BAD_ARG,
+        VCLA_REQUIRE(!(a->a_row_ssq && a->ds_splitk > 1 && !a->ds_raw_partials), VCLA_ERR_BAD_ARG,
                      "gemm: a_row_ssq (deferred RMSNorm of the A operand) cannot be combined with ds_splitk > 1: the split-K reduce launch does not apply rstd");
         VCLA_REQUIRE(a->ds_splitk <= 1 || (a->epilogue == VCLA_EPI_NONE && a->ds_splitk <= 16 && a->N % 4 == 0 && (a->ldc % 4 == 0 || !a->C) && a->splitk_ws &&
                                            a->splitk_ws_bytes >= (size_t)a->ds_splitk * a->M * a->N * 4 && (!a->residual || a->ldr % 4 == 0) &&

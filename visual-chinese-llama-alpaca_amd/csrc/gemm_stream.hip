@@ -37,9 +37,9 @@ __device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 // ring depth: as many stages in flight as fit a ~200-register budget next to the accumulators (acc = NT*MT*4 registers,
 // a stage = (KS*MT + NT)*4), a power of two where possible (K / 256 stages per wave is a power of two for K = 4096: the peeled
 // tail then issues no loads), at most 4
-constexpr int ds_depth(int MT, int NT, bool FP8) {
+constexpr int ds_depth(int MT, int NT, bool FP8, int budget = 0) {
     const int acc = NT * MT * 4, st = ((FP8 ? 2 : 1) * MT + NT) * 4;
-    const int d = ((FP8 ? 176 : 200) - acc) / st;   // fp8: the in-register conversion needs temporaries
+    const int d = ((budget ? budget : (FP8 ? 176 : 200)) - acc) / st;   // fp8: the in-register conversion needs temporaries
     return d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1));   // 4 stages x 8 waves already keep > 100 KiB per CU in flight
 }
 
@@ -86,11 +86,11 @@ __device__ __forceinline__ void ds_row_rstd(const vcla_gemm_args& a, const DsCtx
 
 // One chunk of NT weight tiles [c0, c0 + NT) x all rows, K stages wave, wave + 8, ... of this wave; then the cross-wave reduction
 // and the epilogue.  MT = 16-row tiles of A; FP8: W_q8_frag (two k-steps per 16-byte lane load) instead of W_frag.
-template <int EPI, typename OutT, int MT, int NT, bool FP8>
+template <int EPI, typename OutT, int MT, int NT, bool FP8, int BUD = 0>
 __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, float* rstd_s, bool first) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;       // tiles per epilogue unit (SwiGLU: gate tile + up tile)
     constexpr int KS = FP8 ? 2 : 1;
-    constexpr int D = ds_depth(MT, NT, FP8);
+    constexpr int D = ds_depth(MT, NT, FP8, BUD);
     static_assert(NT % TPU == 0, "SwiGLU chunks hold whole gate/up pairs");
     f32x4_t acc[NT][MT];
 #pragma unroll
@@ -217,14 +217,19 @@ __device__ __forceinline__ void ds_chunk(const DsCtx& c, int c0, f32x4_t* slab, 
 
 // A workgroup walks its share of tiles in chunks of at most 4 tiles (6 = three gate/up pairs for SwiGLU); every chunk size has
 // its own branch-free instantiation of the loop.
-template <int EPI, typename OutT, int MT, bool FP8>
+// WIDE (epilogue NONE, split-K with raw partials: the qkv GEMM whose consumer -- the decode attention -- sums the slices itself): chunks
+// of up to 6 tiles, so that a group of 2 workgroups covers its 6 tiles of the 768 in ONE pass over its half of K and each CU reads half
+// the activation panel once (the point of the exercise: a CU's intake, not HBM, bounds these GEMMs).  A separate instantiation: the
+// default kernel's code (and register allocation) stays what it was.
+template <int EPI, typename OutT, int MT, bool FP8, bool WIDE = false>
 __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_args a, int units_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ds_smem[];
     f32x4_t* slab = reinterpret_cast<f32x4_t*>(ds_smem);      // [wave][unit in round][tile of unit][lane]
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
     float* rstd_s = reinterpret_cast<float*>(ds_smem + (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t));   // [64] behind the slabs
-    constexpr int NTW = EPI == VCLA_EPI_SWIGLU ? 6 : 4;
+    constexpr int NTW = (EPI == VCLA_EPI_SWIGLU || WIDE) ? 6 : 4;
     constexpr int KS = FP8 ? 2 : 1;
+    static_assert(!WIDE || EPI == VCLA_EPI_NONE, "wide chunks: epilogue NONE");
     DsCtx c;
     c.lane = threadIdx.x & 63;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,6 +256,10 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
             else if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
         } else {
+            if constexpr (WIDE) {      // the launcher guarantees whole chunks of 6 (one instantiation: no spill-prone dispatch over six variants)
+                ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);   // ring depth 2 (a third stage next to 96 accumulators spills 21 registers)
+                continue;
+            }
             if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
@@ -326,13 +335,25 @@ template <int EPI, typename OutT, int MT, bool FP8>
 static int ds_launch(const vcla_gemm_args* a, int units, int grid, hipStream_t s) {
     constexpr int TPU = EPI == VCLA_EPI_SWIGLU ? 2 : 1;
     const size_t lds = (size_t)DS_WAVES * DS_ROUND * TPU * 64 * sizeof(f32x4_t) + 64 * sizeof(float);   // 64 KiB (128 KiB for SwiGLU) + rstd[64]
+    if constexpr (EPI == VCLA_EPI_NONE && MT >= 3 && sizeof(OutT) == 2) {
+        const int groups_ = grid / (a->ds_splitk > 1 ? a->ds_splitk : 1);
+        if (a->ds_splitk > 1 && a->ds_raw_partials && units % groups_ == 0 && (units / groups_) % 6 == 0) {
+            // raw fp32 slices for a consumer that sums them (vcla_attn_decode_fused_parts), every tile group a whole number of 6-tile chunks: the wide kernel
+            auto kw = gemm_dstream_kernel<EPI, OutT, MT, FP8, true>;
+            static bool attr_w[VCLA_MAX_DEVICES] = {};
+            { const int rc_ = vcla_raise_dyn_lds((const void*)kw, lds, attr_w); if (rc_) return rc_; }
+            kw<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
+            VCLA_CHECK_LAUNCH("gemm_dstream_kernel<wide>");
+            return VCLA_OK;
+        }
+    }
     auto kern = gemm_dstream_kernel<EPI, OutT, MT, FP8>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     kern<<<grid, DS_WAVES * 64, lds, s>>>(*a, units);
     VCLA_CHECK_LAUNCH("gemm_dstream_kernel");
     if constexpr (EPI == VCLA_EPI_NONE) {
-        if (a->ds_splitk > 1) {
+        if (a->ds_splitk > 1 && !a->ds_raw_partials) {
             const int64_t work = (int64_t)a->M * (a->N / 4);
             ds_reduce_kernel<OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, a->ds_splitk);
             VCLA_CHECK_LAUNCH("ds_reduce_kernel");

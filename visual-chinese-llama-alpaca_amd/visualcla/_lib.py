@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("a_norm_eps", C.c_float),
         ("A_q8", C.c_void_p), ("a_scale", C.c_void_p),
         ("ds_splitk", C.c_int),
+        ("ds_raw_partials", C.c_int),
     ]
 
 
@@ -126,6 +127,7 @@ SYMBOLS = {
     "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
+    "vcla_attn_decode_fused_parts": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
     "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
     "vcla_sample": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(SampleArgs), _vp, _vp]),
     "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
@@ -254,7 +256,7 @@ def quant_fp8_rows(x):
 def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=False, out=None, force_kernel=0,
          group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None,
          post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None, a_frag=None, c_frag=None, m=None,
-         c_frag_gamma=None, c_row_ssq=None, a_row_ssq=None, a_norm_eps=0.0, a_q8=None, a_scale=None, ds_splitk=0):
+         c_frag_gamma=None, c_row_ssq=None, a_row_ssq=None, a_norm_eps=0.0, a_q8=None, a_scale=None, ds_splitk=0, ds_raw_partials=False):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out].  a_frag ([K/32, MT, 64, 8], with m = M) selects
     the streaming decode kernel; c_frag (same layout over N_out) receives a fragment-major copy of the output."""
     lib = load()
@@ -276,6 +278,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args.A_frag, args.C_frag = ptr(a_frag), ptr(c_frag)
     args.A_q8, args.a_scale = ptr(a_q8), ptr(a_scale)
     args.ds_splitk = int(ds_splitk)
+    args.ds_raw_partials = int(bool(ds_raw_partials))
     args.c_frag_gamma, args.c_row_ssq, args.a_row_ssq = ptr(c_frag_gamma), ptr(c_row_ssq), ptr(a_row_ssq)
     args.a_row_ssq_parts, args.a_norm_eps = (a_row_ssq.shape[1] if a_row_ssq is not None else 0), float(a_norm_eps)
     args.W, args.bias = ptr(w_packed), ptr(bias)
