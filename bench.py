@@ -212,9 +212,14 @@ def vit_gemm_roofline(model, B: int = 64, n_rep: int = 20):
     sec = _event_time(run, n_rep) / L
     flops = 2.0 * M * I * D
     tf = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_mfma256_kernel<QUICK_GELU> (ViT fc1, M={M} N={I} K={D}; one launch of 257-row tiles, L2-prefetch form)",
-            "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
-            "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
+    out = {"bound": "mfma", "kernel": f"gemm_mfma256_kernel<QUICK_GELU> (ViT fc1, M={M} N={I} K={D}; one launch of 257-row tiles, L2-prefetch form)",
+           "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+           "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L}
+    # the same launch inside the B = 64 workload (grid = B x N/256 tiles of 512 threads)
+    us_model, us_src = _in_model_us("bench_b64_by_grid.txt", "gemm_mfma256_kernel<1", B * (I // 256) * 512) if B == 64 else (None, None)
+    if us_model:
+        out.update(avg_launch_us_in_model=us_model, frac_in_model=round(flops / (us_model * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4), in_model_source=us_src)
+    return out
 
 
 def fp8_gemm_roofline(model, M: int = 8192, n_rep: int = 5):
