@@ -21,13 +21,13 @@ DEV = "cuda:0"
 def rnd(*s, scale=1.0): return (torch.randn(*s, device=DEV) * scale).to(torch.bfloat16)
 def packw(n, k):
     w = torch.zeros((n + 127) // 128 * 128, k, dtype=torch.bfloat16, device=DEV); w[:n] = rnd(n, k, scale=0.02); return w
-print(f"==== {ABL[abl]}")
+print(f"==== {ABL[abl]}; VCLA_GEMM_PF={os.environ.get('VCLA_GEMM_PF', '1 (default)')}")
 for tag, M, N, K, epi in (("vit qkv", 16384, 3072, 1024, 0), ("vit fc1", 16384, 4096, 1024, 1), ("vit fc2", 16384, 1024, 4096, 0),
-                          ("llama qkv prefill", 8192, 12288, 4096, 0)):
+                          ("vit fc1, 257-row tiles", 16448, 4096, 1024, 1), ("llama qkv prefill", 8192, 12288, 4096, 0)):
     a, w = rnd(M, K), packw(N, K)
     bias = torch.randn(N, device=DEV)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    nwg = (M // 256) * ((N + 255) // 256)
+    nwg = (M // 257 if M % 257 == 0 else M // 256) * ((N + 255) // 256)
     tl = torch.zeros(nwg, 8, dtype=torch.int64, device=DEV)
     for _ in range(3):
         _lib.gemm(a, w, N, bias=bias, epilogue=epi, out=out, force_kernel=4)
