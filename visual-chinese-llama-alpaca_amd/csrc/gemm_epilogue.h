@@ -1,6 +1,7 @@
 // gemm_epilogue.h -- epilogue shared by every MFMA GEMM kernel of libvisualcla_hip.so (gemm.hip, gemm_stream.hip).
 #pragma once
 #include "vcla_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ shared epilogue math
 template <int EPI> __device__ __forceinline__ float epi_act(float x) {
@@ -17,8 +18,22 @@ __device__ __forceinline__ int64_t remap_row(const vcla_gemm_args& a, int m) {
 // ---- shared MFMA epilogue.  The wave owns MI x 4 accumulator tiles of 16x16 (operands swapped, see header):
 // acc[i][j][r] = C[m][n] with m = mw + i*16 + (lane & 15), n = nw + j*16 + (lane >> 4)*4 + r  -> 4 consecutive
 // columns per lane (8/16-byte stores); SWIGLU tiles (2j, 2j+1) = (gate, up) of output column nw/2 + j*16 + ...
+// the lane's bias values (NJ tiles x 4 columns, 0 where there is none): what gemm_epilogue loads first.  A kernel whose K loop is long may
+// fetch them BEFORE the loop and hand them over (`bia_pre`), so that the epilogue does not open with a dependent round trip to L2 / HBM.
+template <int EPI, int NJ>
+__device__ __forceinline__ void gemm_epilogue_bias(const vcla_gemm_args& a, int nw, int lane, float (&bia)[NJ][4]) {
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nw + j * 16 + nq;            // packed column (SwiGLU: gate tiles 2jo, up tiles 2jo + 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bia[j][r] = (a.bias && (EPI == VCLA_EPI_SWIGLU || n + r < a.N)) ? a.bias[n + r] : 0.f;
+    }
+}
+
 template <int EPI, typename OutT, int MI, int NJ = 4>
-__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane, int m_end = 0x7fffffff) {
+__device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane, int m_end = 0x7fffffff,
+                                              const float (*bia_pre)[4] = nullptr) {
     const int mrow = lane & 15, nq = (lane >> 4) * 4;
     OutT* Cg = (OutT*)a.C;
     constexpr bool kF32 = sizeof(OutT) == 4;
@@ -38,7 +53,7 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
         const int n = nw + j * 16 + nq;            // packed column (SwiGLU: gate tiles 2jo, up tiles 2jo + 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            bia[j][r] = (a.bias && (EPI == VCLA_EPI_SWIGLU || n + r < a.N)) ? a.bias[n + r] : 0.f;
+            bia[j][r] = bia_pre ? bia_pre[j][r] : ((a.bias && (EPI == VCLA_EPI_SWIGLU || n + r < a.N)) ? a.bias[n + r] : 0.f);
             wsc[j][r] = a.w_scale ? a.w_scale[n + r] : 1.f;      // n + r < N_pad always
         }
     }
@@ -88,6 +103,76 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                           n_first + NOUT * 16 <= n_out;        // wave-uniform: the whole tile row is inside the matrix
         if (wide) {
             const int row_ = lane >> 4;
+            // ---- fast form (no fp8 scales, residual rows 8-byte loadable): every wave-uniform question -- bias? residual? -- is answered ONCE,
+            // out here, and the element loops below are straight-line code.  The general form further down asks them per element (through
+            // tile_vals); measured with per-workgroup stamps on the 256 x 256 kernel (profiles/r03_gemm256_ab.txt, run 33): of a tile's 6.4 us
+            // epilogue (ViT qkv, bias only) 3.2 us were that arithmetic and only 1.7 us the stores.
+#ifdef VCLA_EPI_NO_FAST      // A/B builds only (tools/debug): the general form for every tile
+            if (false) {
+#else
+            if (!a.w_scale && !a.a_scale && (!a.residual || vec_r) && a.c_group_rows <= 0) {
+#endif
+                auto run = [&](auto hb_, auto hr_) {
+                    constexpr bool kB = decltype(hb_)::value, kR = decltype(hr_)::value;
+                    const bf16_t* Rg = (const bf16_t*)a.residual;
+                    // the residual values of HB row tiles at a time, all requested before the first of their stores (the residual may alias C -- in
+                    // place -- so a load issued after a store could not be hoisted above it): MI / HB round trips per tile instead of MI.  (All MI at
+                    // once costs 64 registers: the persistent form of the 256 x 256 kernel then spilled 20 - 54 of them.)
+                    constexpr int HB = MI >= 4 ? (EPI == VCLA_EPI_GELU_ERF ? 2 : 4) : MI;      // erf-GELU needs its temporaries: 2 row tiles per batch
+#pragma unroll
+                    for (int i0 = 0; i0 < MI; i0 += HB) {
+                        uint2 rr[kR ? HB : 1][NOUT];
+                        if constexpr (kR) {
+#pragma unroll
+                            for (int ii = 0; ii < HB; ++ii) {
+                                int m = mw + (i0 + ii) * 16 + mrow;
+                                m = m < a.M ? m : a.M - 1;
+#pragma unroll
+                                for (int jo = 0; jo < NOUT; ++jo) rr[ii][jo] = *reinterpret_cast<const uint2*>(Rg + (int64_t)m * a.ldr + n_first + jo * 16 + nq);
+                            }
+                        }
+#pragma unroll
+                        for (int ii = 0; ii < HB; ++ii) {
+                            const int i = i0 + ii;
+                            const int m = mw + i * 16 + mrow;
+                            if (m >= a.M || m >= m_end) continue;
+#pragma unroll
+                            for (int p = 0; p < NOUT / 2; ++p) {
+                                float v[2][4];
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const int jo = 2 * p + t;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        if constexpr (EPI == VCLA_EPI_SWIGLU) {
+                                            float gt = acc[i][2 * jo][r], up = acc[i][2 * jo + 1][r];
+                                            if constexpr (kB) { gt += bia[2 * jo][r]; up += bia[2 * jo + 1][r]; }
+                                            v[t][r] = act_silu(gt) * up;
+                                        } else {
+                                            float x = acc[i][jo][r];
+                                            if constexpr (kB) x += bia[jo][r];
+                                            v[t][r] = epi_act<EPI>(x);
+                                        }
+                                    }
+                                    if constexpr (kR) {
+                                        v[t][0] += __uint_as_float(rr[ii][jo].x << 16); v[t][1] += __uint_as_float(rr[ii][jo].x & 0xffff0000u);
+                                        v[t][2] += __uint_as_float(rr[ii][jo].y << 16); v[t][3] += __uint_as_float(rr[ii][jo].y & 0xffff0000u);
+                                    }
+                                }
+                                const unsigned a0 = pack_bf2(v[0][0], v[0][1]), a1 = pack_bf2(v[0][2], v[0][3]);
+                                const unsigned b0 = pack_bf2(v[1][0], v[1][1]), b1 = pack_bf2(v[1][2], v[1][3]);
+                                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                                const int n = n_first + (2 * p + (row_ & 1)) * 16 + (row_ >> 1) * 8;
+                                *reinterpret_cast<uint4*>(Cg + (int64_t)m * a.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            }
+                        }
+                    }
+                };
+                if (a.bias) { if (a.residual) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+                else { if (a.residual) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = mw + i * 16 + mrow;
@@ -97,14 +182,22 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
 #pragma unroll
                 for (int p = 0; p < NOUT / 2; ++p) {
                     float v0[4], v1[4];
+#if defined(VCLA_G2_EPI_ABLATE) && VCLA_G2_EPI_ABLATE == 2     // timing experiment: raw accumulators, no bias / activation / residual
+                    for (int r = 0; r < 4; ++r) { v0[r] = acc[i][2 * p][r]; v1[r] = acc[i][2 * p + 1][r]; }
+#else
                     tile_vals(i, 2 * p, m, ascale, v0);
                     tile_vals(i, 2 * p + 1, m, ascale, v1);
+#endif
                     unsigned a0 = pack_bf2(v0[0], v0[1]), a1 = pack_bf2(v0[2], v0[3]);
                     unsigned b0 = pack_bf2(v1[0], v1[1]), b1 = pack_bf2(v1[2], v1[3]);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     const int n = n_first + (2 * p + (row_ & 1)) * 16 + (row_ >> 1) * 8;
+#if defined(VCLA_G2_EPI_ABLATE) && VCLA_G2_EPI_ABLATE == 1     // timing experiment: everything but the store itself
+                    asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]), "v"(n), "v"(crow));
+#else
                     *reinterpret_cast<uint4*>(Cg + crow * a.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+#endif
                 }
             }
             return;

@@ -58,24 +58,12 @@ extern "C" int vcla_debug_set_timeline(unsigned long long* p) { return (int)hipM
 // fragment one more ds_read per wave and k-step, and its 16 output tiles are dealt two to each wave (+2 MFMAs on 32, the W fragments
 // are already in registers).  Rows 1..15 of the strip are rows of the NEXT tile or stale LDS: computed, never stored (m_end).
 template <int EPI, typename OutT, bool SGB, bool PF = false, int XR = 0>
-__global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad, int stagger = 0) {
+__global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
     static_assert(XR == 0 || PF, "257-row tiles exist in the PF form only");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];  // [buf][A|W][32 KiB] (+ 512 B sink, PF); XR: A = 34 KiB
     constexpr int G2_TM = G2_BM + XR;                                      // rows of the output tile
     constexpr int A_BYTES = XR ? 272 * 128 : G2_TILE_BYTES;                // A region of one stage (XR: 17 strips of 16 rows)
     constexpr int STAGE = A_BYTES + G2_TILE_BYTES;
-    if constexpr (PF) {
-        // Phase stagger (launches of >= 3 rounds): the workgroups of a round run in lockstep and end it with a 6 - 8 us burst of output
-        // stores that is HBM-write-bound (32 MiB per round at ~5.3 TB/s) while the K loops before it leave HBM idle.  The first-round
-        // workgroups of XCD x wait (x & 3) * stagger ticks (100 MHz clock) before they start: the four phase groups keep their offsets
-        // for the rest of the launch (a CU takes its next tile when it is done), so a quarter of the chip stores while three quarters
-        // compute.  By XCD, not by workgroup: the workgroups that share operand panels -- an XCD's -- stay in step (L2 line sharing,
-        // prefetch touches).
-        if (stagger > 0 && blockIdx.x < 256) {
-            const unsigned long long t0 = wall_clock64(), want = (unsigned long long)((blockIdx.x & 3) * stagger);
-            while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     G2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = PF ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -162,6 +150,10 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         f32x4_t accx[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};   // XR: tiles (2 wm, 2 wm + 1) of the wave's columns, strip 16
+        // the lane's 16 bias values are requested HERE, before the K loop (16 registers carried through it): fetched after the loop they cost the
+        // epilogue a dependent round trip before its first store (~2 us of a 5 us epilogue)
+        float bia_pre[4][4];
+        gemm_epilogue_bias<EPI, 4>(a, n0 + wn * 64, lane, bia_pre);
         touch(1);
         issue_pf(0, 0);
         touch(2);
@@ -221,8 +213,15 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         }
         g2_vmcnt<0>();                                           // no DMA may land in LDS after the workgroup has given it up
         G2_STAMP(2);
-        gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
-        if constexpr (XR) gemm_epilogue<EPI, OutT, 1, 2>(a, accx, m0 + 256, n0 + wn * 64 + wm * 32, lane, m0 + 257);
+        gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, 0x7fffffff, bia_pre);
+        if constexpr (XR) {
+            float bx[2][4];          // the strip's two tiles are tiles (2 wm, 2 wm + 1) of the wave: selects with literal indices, not a pointer into the registers
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bx[t][r] = wm == 0 ? bia_pre[t][r] : bia_pre[2 + t][r];
+            gemm_epilogue<EPI, OutT, 1, 2>(a, accx, m0 + 256, n0 + wn * 64 + wm * 32, lane, m0 + 257, bx);
+        }
         G2_STAMP(3);
 #ifdef VCLA_G2_TIMELINE
         __builtin_amdgcn_s_waitcnt(0);
@@ -443,7 +442,6 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     static const int pf = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 1;
     static const int xr_env = getenv("VCLA_GEMM_XR") ? atoi(getenv("VCLA_GEMM_XR")) : 1;   // 0: 256-row tiles also when M % 257 == 0
     const int nt = tiles_m * tiles_n;
-    static const int stg = getenv("VCLA_GEMM_STAGGER") ? atoi(getenv("VCLA_GEMM_STAGGER")) : 0;   // ticks of 10 ns per phase group (see the kernel)
     if (pf && SGB && a->K >= 3 * GM_BK) {   // force_kernel 5 (SGB = false) stays the plain form: both forms remain under test
         if (xr_env && vcla_gemm_tile257(a)) {   // M = B * 257 (the ViT's token count): 257-row tiles, no ragged tail
             auto kx = gemm_mfma256_kernel<EPI, OutT, SGB, true, 1>;
@@ -451,18 +449,18 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
             static bool attr_x[VCLA_MAX_DEVICES] = {};
             { const int rc_ = vcla_raise_dyn_lds((const void*)kx, ldx, attr_x); if (rc_) return rc_; }
             const int tmx = a->M / 257;
-            kx<<<tmx * tiles_n, 512, ldx, s>>>(*a, tmx, tiles_n, n_pad, tmx * tiles_n >= 3 * 256 ? stg : 0);
+            kx<<<tmx * tiles_n, 512, ldx, s>>>(*a, tmx, tiles_n, n_pad);
             VCLA_CHECK_LAUNCH("gemm_mfma256_kernel<PF, 257>");
             return VCLA_OK;
         }
         auto kpf = gemm_mfma256_kernel<EPI, OutT, SGB, true>;
         static bool attr_pf[VCLA_MAX_DEVICES] = {};
         { const int rc_ = vcla_raise_dyn_lds((const void*)kpf, lds + 512, attr_pf); if (rc_) return rc_; }
-        kpf<<<nt, 512, lds + 512, s>>>(*a, tiles_m, tiles_n, n_pad, nt >= 3 * 256 ? stg : 0);
+        kpf<<<nt, 512, lds + 512, s>>>(*a, tiles_m, tiles_n, n_pad);
         VCLA_CHECK_LAUNCH("gemm_mfma256_kernel<PF>");
         return VCLA_OK;
     }
-    kern<<<(pg && nt > 256) ? 256 : nt, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad, 0);   // one workgroup per CU, persistent over tiles
+    kern<<<(pg && nt > 256) ? 256 : nt, 512, lds, s>>>(*a, tiles_m, tiles_n, n_pad);   // one workgroup per CU, persistent over tiles
     VCLA_CHECK_LAUNCH("gemm_mfma256_kernel");
     return VCLA_OK;
 }

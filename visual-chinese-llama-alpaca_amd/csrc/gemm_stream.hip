@@ -39,6 +39,7 @@ __device__ __forceinline__ bf16x8_t ds_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 // tail then issues no loads), at most 4
 constexpr int ds_depth(int MT, int NT, bool FP8, int budget = 0) {
     const int acc = NT * MT * 4, st = ((FP8 ? 2 : 1) * MT + NT) * 4;
+    if (FP8 && MT == 3 && NT == 6) return 1;        // (fp8 gate/up at 33 - 48 rows: a second stage spills two registers to scratch -- no product kernel uses scratch)
     const int d = ((budget ? budget : (FP8 ? 176 : 200)) - acc) / st;   // fp8: the in-register conversion needs temporaries
     return d >= 4 ? 4 : (d >= 3 ? 3 : (d >= 2 ? 2 : 1));   // 4 stages x 8 waves already keep > 100 KiB per CU in flight
 }
