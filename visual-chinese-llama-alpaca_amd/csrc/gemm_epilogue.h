@@ -31,7 +31,9 @@ __device__ __forceinline__ void gemm_epilogue_bias(const vcla_gemm_args& a, int 
     }
 }
 
-template <int EPI, typename OutT, int MI, int NJ = 4>
+// SCALES: the caller is the fp8 x fp8 kernel (w_scale / a_scale always present): its fast form is instantiated INSTEAD of the plain one, so
+// that no kernel carries both (the persistent kernels have no registers to spare: with both, they spilled 20 values to scratch).
+template <int EPI, typename OutT, int MI, int NJ = 4, bool SCALES = false>
 __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (&acc)[MI][NJ], int mw, int nw, int lane, int m_end = 0x7fffffff,
                                               const float (*bia_pre)[4] = nullptr) {
     const int mrow = lane & 15, nq = (lane >> 4) * 4;
@@ -103,32 +105,36 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                           n_first + NOUT * 16 <= n_out;        // wave-uniform: the whole tile row is inside the matrix
         if (wide) {
             const int row_ = lane >> 4;
-            // ---- fast form (no fp8 scales, residual rows 8-byte loadable): every wave-uniform question -- bias? residual? -- is answered ONCE,
+            // ---- fast form (residual rows 8-byte loadable): every wave-uniform question -- bias? residual? fp8 scales? -- is answered ONCE,
             // out here, and the element loops below are straight-line code.  The general form further down asks them per element (through
             // tile_vals); measured with per-workgroup stamps on the 256 x 256 kernel (profiles/r03_gemm256_ab.txt, run 33): of a tile's 6.4 us
             // epilogue (ViT qkv, bias only) 3.2 us were that arithmetic and only 1.7 us the stores.
 #ifdef VCLA_EPI_NO_FAST      // A/B builds only (tools/debug): the general form for every tile
             if (false) {
 #else
-            if (!a.w_scale && !a.a_scale && (!a.residual || vec_r) && a.c_group_rows <= 0) {
+            if ((SCALES ? a.w_scale != nullptr : !a.w_scale && !a.a_scale) && (!a.residual || vec_r) && a.c_group_rows <= 0) {
 #endif
-                auto run = [&](auto hb_, auto hr_) {
-                    constexpr bool kB = decltype(hb_)::value, kR = decltype(hr_)::value;
+                auto run = [&](auto hb_, auto hr_, auto hs_) {
+                    constexpr bool kB = decltype(hb_)::value, kR = decltype(hr_)::value, kS = decltype(hs_)::value;   // bias, residual, fp8 scales
                     const bf16_t* Rg = (const bf16_t*)a.residual;
                     // the residual values of HB row tiles at a time, all requested before the first of their stores (the residual may alias C -- in
                     // place -- so a load issued after a store could not be hoisted above it): MI / HB round trips per tile instead of MI.  (All MI at
                     // once costs 64 registers: the persistent form of the 256 x 256 kernel then spilled 20 - 54 of them.)
-                    constexpr int HB = MI >= 4 ? (EPI == VCLA_EPI_GELU_ERF ? 2 : 4) : MI;      // erf-GELU needs its temporaries: 2 row tiles per batch
+                    constexpr int HB = MI >= 4 ? ((EPI == VCLA_EPI_GELU_ERF && SCALES) ? 1 : ((EPI == VCLA_EPI_GELU_ERF || SCALES) ? 2 : 4)) : MI;      // erf-GELU / the fp8 scales need registers: 2 row tiles per batch
 #pragma unroll
                     for (int i0 = 0; i0 < MI; i0 += HB) {
                         uint2 rr[kR ? HB : 1][NOUT];
-                        if constexpr (kR) {
+                        float asc[kS ? HB : 1];          // fp8 activations: the row's scale (1 when only the weights are fp8)
+                        if constexpr (kR || kS) {
 #pragma unroll
                             for (int ii = 0; ii < HB; ++ii) {
                                 int m = mw + (i0 + ii) * 16 + mrow;
                                 m = m < a.M ? m : a.M - 1;
+                                if constexpr (kS) asc[ii] = a.a_scale ? a.a_scale[m] : 1.f;
+                                if constexpr (kR) {
 #pragma unroll
-                                for (int jo = 0; jo < NOUT; ++jo) rr[ii][jo] = *reinterpret_cast<const uint2*>(Rg + (int64_t)m * a.ldr + n_first + jo * 16 + nq);
+                                    for (int jo = 0; jo < NOUT; ++jo) rr[ii][jo] = *reinterpret_cast<const uint2*>(Rg + (int64_t)m * a.ldr + n_first + jo * 16 + nq);
+                                }
                             }
                         }
 #pragma unroll
@@ -146,10 +152,12 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                                     for (int r = 0; r < 4; ++r) {
                                         if constexpr (EPI == VCLA_EPI_SWIGLU) {
                                             float gt = acc[i][2 * jo][r], up = acc[i][2 * jo + 1][r];
+                                            if constexpr (kS) { gt *= wsc[2 * jo][r] * asc[ii]; up *= wsc[2 * jo + 1][r] * asc[ii]; }
                                             if constexpr (kB) { gt += bia[2 * jo][r]; up += bia[2 * jo + 1][r]; }
                                             v[t][r] = act_silu(gt) * up;
                                         } else {
                                             float x = acc[i][jo][r];
+                                            if constexpr (kS) x *= wsc[jo][r] * asc[ii];
                                             if constexpr (kB) x += bia[jo][r];
                                             v[t][r] = epi_act<EPI>(x);
                                         }
@@ -169,8 +177,13 @@ __device__ __forceinline__ void gemm_epilogue(const vcla_gemm_args& a, f32x4_t (
                         }
                     }
                 };
-                if (a.bias) { if (a.residual) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
-                else { if (a.residual) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+                if constexpr (SCALES) {
+                    if (a.bias) { if (a.residual) run(std::true_type{}, std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}, std::true_type{}); }
+                    else { if (a.residual) run(std::false_type{}, std::true_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}, std::true_type{}); }
+                } else {
+                    if (a.bias) { if (a.residual) run(std::true_type{}, std::true_type{}, std::false_type{}); else run(std::true_type{}, std::false_type{}, std::false_type{}); }
+                    else { if (a.residual) run(std::false_type{}, std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}, std::false_type{}); }
+                }
                 return;
             }
 #pragma unroll

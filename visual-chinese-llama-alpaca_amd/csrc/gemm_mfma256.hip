@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512) void gemm_mfma256_fp8_kernel(vcla_gemm_args a,
                                                                                 0, 127 /* E8M0 1.0 */, 0, 127);
             }
         }
-        gemm_epilogue<EPI, OutT, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        gemm_epilogue<EPI, OutT, 8, 4, true>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
         if (!has_next) break;
         p0 = (nk + p0) & 1;
         tile = next; m0 = nm0; n0 = nn0;
