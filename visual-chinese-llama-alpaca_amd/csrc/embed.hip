@@ -143,6 +143,80 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, void*
     }
 }
 
+// bf16, d/2 a multiple of 8: the same arithmetic on 16-byte chunks -- a thread owns 8 consecutive pair indices of one head (two 16-byte loads
+// of q, two of k, 8 cos / sin values), rotates, stores q in place and k into the cache with 16-byte stores (8-byte stores of e4m3 bytes with
+// KV8, which also writes k back in place); the value row moves as 16-byte chunks.  (The scalar kernel above moved 2 bytes per lane and
+// instruction: 92.9 us per launch at B = 64, T = 128 = 3.6 TB/s for 335 MB.)
+template <bool KV8>
+__global__ __launch_bounds__(256) void rope_kv_vec_kernel(bf16_t* __restrict__ qkv, void* __restrict__ kc_, void* __restrict__ vc_,
+                                                          const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int T_, int H, int d,
+                                                          int ctx_max, int pos0, const int32_t* __restrict__ pos_dev) {
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / T_), t = (int)(row % T_);
+    const int pos = pos0 + (pos_dev ? *pos_dev : 0) + t;
+    const int half = d / 2, cph = half / 8;            // chunks of 8 pair indices per head
+    const int HD = H * d;
+    bf16_t* q = qkv + row * 3 * HD;
+    bf16_t* k = q + HD;
+    const bf16_t* v = k + HD;
+    const float* cs = cos_tab + (int64_t)pos * half;
+    const float* sn = sin_tab + (int64_t)pos * half;
+    auto rot = [](const uint4& lo, const uint4& hi, const float* c, const float* s_, uint4& olo, uint4& ohi) {
+        float a[8], b_[8];
+        bf8_to_f32(lo, a); bf8_to_f32(hi, b_);
+        float r0[8], r1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r0[e] = a[e] * c[e] - b_[e] * s_[e]; r1[e] = b_[e] * c[e] + a[e] * s_[e]; }
+        olo = make_uint4(pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r0[4], r0[5]), pack_bf2(r0[6], r0[7]));
+        ohi = make_uint4(pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3]), pack_bf2(r1[4], r1[5]), pack_bf2(r1[6], r1[7]));
+    };
+    for (int idx = threadIdx.x; idx < H * cph; idx += 256) {
+        const int h = idx / cph, i = (idx % cph) * 8;
+        float c[8], s_[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { c[e] = Act<bf16_t>::rnd(cs[i + e]); s_[e] = Act<bf16_t>::rnd(sn[i + e]); }
+        const int o = h * d + i;
+        uint4 lo, hi;
+        rot(*reinterpret_cast<const uint4*>(q + o), *reinterpret_cast<const uint4*>(q + o + half), c, s_, lo, hi);
+        *reinterpret_cast<uint4*>(q + o) = lo;
+        *reinterpret_cast<uint4*>(q + o + half) = hi;
+        rot(*reinterpret_cast<const uint4*>(k + o), *reinterpret_cast<const uint4*>(k + o + half), c, s_, lo, hi);
+        const int64_t ko = (((int64_t)b * H + h) * ctx_max + pos) * d + i;
+        if constexpr (KV8) {
+            *reinterpret_cast<uint4*>(k + o) = lo;
+            *reinterpret_cast<uint4*>(k + o + half) = hi;
+            unsigned char* kc8 = (unsigned char*)kc_;
+            float f[8];
+            bf8_to_f32(lo, f);
+            unsigned w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            unsigned w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<uint2*>(kc8 + ko) = make_uint2(w0, w1);
+            bf8_to_f32(hi, f);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<uint2*>(kc8 + ko + half) = make_uint2(w0, w1);
+        } else {
+            bf16_t* kc = (bf16_t*)kc_;
+            *reinterpret_cast<uint4*>(kc + ko) = lo;
+            *reinterpret_cast<uint4*>(kc + ko + half) = hi;
+        }
+    }
+    for (int idx = threadIdx.x * 8; idx < HD; idx += 256 * 8) {
+        const int h = idx / d, i = idx % d;
+        const uint4 vv = *reinterpret_cast<const uint4*>(v + idx);
+        const int64_t vo = (((int64_t)b * H + h) * ctx_max + pos) * d + i;
+        if constexpr (KV8) {
+            float f[8];
+            bf8_to_f32(vv, f);
+            unsigned w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            unsigned w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<uint2*>((unsigned char*)vc_ + vo) = make_uint2(w0, w1);
+        } else {
+            *reinterpret_cast<uint4*>((bf16_t*)vc_ + vo) = vv;
+        }
+    }
+}
+
 extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const float* cos_tab,
                                    const float* sin_tab, int B, int T, int H, int d, int ctx_max, int pos0,
                                    const int32_t* pos_dev, int dtype, void* stream) {
@@ -161,7 +235,10 @@ extern "C" int vcla_rope_kv_append(void* qkv, void* k_cache, void* v_cache, cons
     if (dtype == VCLA_F32)
         rope_kv_kernel<float><<<(unsigned)rows, 256, 0, s>>>((float*)qkv, k_cache, v_cache, cos_tab,
                                                              sin_tab, T, H, d, ctx_max, pos0, pos_dev);
-    else if (kv8)
+    else if (d % 16 == 0 && vcla_aligned(qkv, 16) && vcla_aligned(k_cache, 16) && vcla_aligned(v_cache, 16)) {      // bf16, 16-byte chunks
+        if (kv8) rope_kv_vec_kernel<true><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache, cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
+        else rope_kv_vec_kernel<false><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache, cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
+    } else if (kv8)
         rope_kv_kernel<bf16_t, true><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache, cos_tab, sin_tab, T, H, d, ctx_max, pos0, pos_dev);
     else
         rope_kv_kernel<bf16_t><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, k_cache, v_cache,
