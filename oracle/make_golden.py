@@ -151,6 +151,96 @@ CASES = {
 }
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# Edge cases of VisualCLAModel.forward / .generate (modeling_visualcla.py:264-392) the two happy-path files above do not reach.
+# Every entry stores its INPUTS next to the reference's outputs, so the consumers (tests/test_oracle_vs_golden.py on the CPU,
+# tests/test_gpu_model.py on the MI355X) replay exactly what the reference saw.
+# --------------------------------------------------------------------------------------------------------------------
+def _left_pad(ids, mask, row, k):
+    """left-pad `row` by k pad tokens (id 0), dropping its last k ids -- the layout a batched tokenizer with padding_side='left' makes"""
+    ids, mask = ids.clone(), mask.clone()
+    ids[row] = torch.cat([torch.zeros(k, dtype=ids.dtype), ids[row, :-k]])
+    mask[row, :k] = 0
+    return ids, mask
+
+
+def _greedy(model, n_new, **kw):
+    from transformers import GenerationConfig
+    gen = GenerationConfig(max_new_tokens=n_new, min_new_tokens=n_new, do_sample=False, num_beams=1,
+                           bos_token_id=1, eos_token_id=None, pad_token_id=0)
+    with torch.no_grad():
+        return model.generate(generation_config=gen, **kw).detach().to(torch.int64)
+
+
+def edge_cases(mods):
+    out = {}
+
+    def put(case, **arrs):
+        for k, v in arrs.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach()
+                v = v.numpy() if v.dtype in (torch.int64, torch.int32) else v.float().numpy().astype(np.float32)
+            out[f"{case}__{k}"] = np.asarray(v)
+
+    for cname, mk, T, npre, k_pad, n_new in (("tiny", O.cfg_tiny, 34, 5, 3, 6), ("small", O.cfg_small, 48, 6, 5, 5)):
+        cfg = mk()
+        W = O.make_weights(cfg, seed=0)
+        model = build_reference_model(mods, cfg, W)
+        px, ids, mask = O.make_inputs(cfg, 2, T, n_prefix=npre)
+        # (1) left-padded batch (:307-312 -> HF mask + positions): forward logits and greedy ids
+        lids, lmask = _left_pad(ids, mask, 1, k_pad)
+        with torch.no_grad():
+            lg = model(input_ids=lids, pixel_values=px, attention_mask=lmask, use_cache=False, return_dict=True).logits
+        put(f"leftpad_{cname}", input_ids=lids, attention_mask=lmask, logits=lg,
+            generated=_greedy(model, n_new, input_ids=lids, pixel_values=px, attention_mask=lmask), meta=np.array([T, npre, n_new]))
+        if cname != "tiny":
+            continue
+        V = cfg.text.vocab_size
+        g = torch.Generator().manual_seed(11)
+        # (2) text-only forward (:317-319), plain and left-padded
+        txt = torch.randint(3, 300, (2, 9), generator=g)
+        tmask = torch.ones_like(txt)
+        tmask[1, :2] = 0
+        with torch.no_grad():
+            lg0 = model(input_ids=txt, attention_mask=torch.ones_like(txt), return_dict=True).logits
+            lg1 = model(input_ids=txt, attention_mask=tmask, return_dict=True).logits
+        put("textonly", input_ids=txt, attention_mask=tmask, logits_full_mask=lg0, logits=lg1)
+        # (3) labels -> loss with the image in its slots (image_at_head=False: labels pass through, :321-328)
+        labels = ids.clone()
+        p0 = 1 + npre
+        labels[:, : p0 + cfg.resampler.num_query_tokens + 2] = -100          # supervise the text after </img> only
+        labels[1, -2:] = -100
+        with torch.no_grad():
+            o = model(input_ids=ids, pixel_values=px, attention_mask=mask, labels=labels, return_dict=True)
+        put("slot_labels", input_ids=ids, attention_mask=mask, labels=labels, logits=o.logits, loss=o.loss.reshape(1))
+        # (4) image_at_head=True with labels (:290-291, :308-310, :313-315): logits AND loss, plus greedy ids in that mode
+        hids = torch.cat([torch.tensor([[1, cfg.img_start_token_id, cfg.img_end_token_id]] * 2), torch.randint(3, 300, (2, 9), generator=g)], dim=1)
+        hmask = torch.ones_like(hids)
+        hlabels = hids.clone()
+        hlabels[:, 0] = -100                 # labels[:, 1] stays supervised: the reference's label placement (:315) then shows in the loss
+        hlabels[0, 7] = -100
+        model.image_at_head = True
+        with torch.no_grad():
+            o = model(input_ids=hids, pixel_values=px, attention_mask=hmask, labels=hlabels, return_dict=True)
+        put("head_labels", input_ids=hids, attention_mask=hmask, labels=hlabels, logits=o.logits, loss=o.loss.reshape(1),
+            generated=_greedy(model, 5, input_ids=hids, pixel_values=px, attention_mask=hmask))
+        model.image_at_head = False
+        # (5) past_key_values pass-through (:321-328): prompt with use_cache=True, then two single-token forwards on the cache
+        with torch.no_grad():
+            first = model(input_ids=ids[:, :-2], pixel_values=px, attention_mask=mask[:, :-2], use_cache=True, return_dict=True)
+            s1 = model(input_ids=ids[:, -2:-1], attention_mask=mask[:, :-1], past_key_values=first.past_key_values, use_cache=True, return_dict=True)
+            s2 = model(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=s1.past_key_values, use_cache=True, return_dict=True)
+        put("cache", input_ids=ids, attention_mask=mask, prompt_logits=first.logits, step1_logits=s1.logits, step2_logits=s2.logits)
+        # (6) a batch where one row has no image slot (:297-299: that row's embeds pass through untouched)
+        mids = ids.clone()
+        mids[1] = torch.randint(3, 300, (T,), generator=g)
+        with torch.no_grad():
+            lg = model(input_ids=mids, pixel_values=px, attention_mask=mask, return_dict=True).logits
+        put("mixed_rows", input_ids=mids, attention_mask=mask, logits=lg,
+            generated=_greedy(model, 4, input_ids=mids, pixel_values=px, attention_mask=mask))
+    return out
+
+
 def main():
     mods = load_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -171,6 +261,10 @@ def main():
         np.savez_compressed(path, **arrs)
         print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); taps: {sorted(arrs)}")
         print("   logits std", float(taps['logits'].std()), "generated", taps["generated"].tolist())
+    edge = edge_cases(mods)
+    path = os.path.join(outdir, "ref_edge_cases.npz")
+    np.savez_compressed(path, **edge)
+    print(f"edge cases: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB): {sorted(edge)}")
 
 
 if __name__ == "__main__":

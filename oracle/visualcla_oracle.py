@@ -31,6 +31,7 @@ dependency ``transformers`` (setup.py:13 ``>= 4.29.0``; 5.15.0 installed)):
   llama_forward          hf:llama/modeling_llama.py:347-418
   lm_head                hf:llama/modeling_llama.py:478-480
   visualcla_forward      models/visualcla/modeling_visualcla.py:264-330
+  causal_lm_loss         hf:loss/loss_utils.py ForCausalLMLoss (labels branch of :321-328)
   visualcla_generate     models/visualcla/modeling_visualcla.py:334-392 +
                          hf:generation/utils.py greedy loop (argmax of fp32 last-token logits)
 
@@ -412,10 +413,11 @@ def image_embeds(pixel_values: Tensor, W: Dict[str, Tensor], cfg: OracleCfg,
 # embed + splice
 # --------------------------------------------------------------------------
 def embed_and_splice(input_ids: Tensor, img_emb: Optional[Tensor], W: Dict[str, Tensor],
-                     cfg: OracleCfg, dtype=torch.float32) -> Tensor:
+                     cfg: OracleCfg, dtype=torch.float32, need_img_token: bool = True) -> Tensor:
     """embed_tokens gather, then (image_at_head=False branch) overwrite the Q rows after the
     <img> token with the image embeds; ValueError if the id at p0+Q+1 is not </img>
-    (modeling_visualcla.py:292-305)."""
+    (modeling_visualcla.py:292-305).  forward() leaves a row alone unless it holds BOTH an <img> and an <img_token>
+    (:297); generate() only asks for the <img> (:363): `need_img_token=False`."""
     emb = W["text_model.model.embed_tokens.weight"].to(dtype)[input_ids]
     if img_emb is None:
         return emb
@@ -423,7 +425,7 @@ def embed_and_splice(input_ids: Tensor, img_emb: Optional[Tensor], W: Dict[str, 
     for ids, e, im in zip(input_ids, emb, img_emb):
         Q = im.shape[0]
         pos = torch.where(ids == cfg.img_start_token_id)[0]
-        if len(pos) == 0 or not bool((ids == cfg.img_token_id).any()):
+        if len(pos) == 0 or (need_img_token and not bool((ids == cfg.img_token_id).any())):
             out.append(e)
             continue
         p0 = int(pos[0])
@@ -527,31 +529,59 @@ def _cast_weights(W: Dict[str, Tensor], dtype) -> Dict[str, Tensor]:
     return W if dtype == torch.float32 else {k: v.to(dtype) for k, v in W.items()}
 
 
-def visualcla_forward(input_ids: Tensor, pixel_values: Optional[Tensor], attention_mask: Tensor,
+def causal_lm_loss(logits: Tensor, labels: Tensor) -> Tensor:
+    """hf:loss/loss_utils.py ForCausalLMLoss (what LlamaForCausalLM.forward(labels=...) returns, reached from
+    modeling_visualcla.py:321-328): fp32 logits, labels shifted left by one (the last position gets -100), mean
+    cross-entropy over the positions whose label is not -100."""
+    lg = logits.float()
+    shifted = F.pad(labels, (0, 1), value=-100)[..., 1:].contiguous()
+    return F.cross_entropy(lg.reshape(-1, lg.shape[-1]), shifted.reshape(-1), ignore_index=-100, reduction="mean")
+
+
+def visualcla_forward(input_ids: Tensor, pixel_values: Optional[Tensor], attention_mask: Optional[Tensor],
                       W: Dict[str, Tensor], cfg: OracleCfg, dtype=torch.float32,
-                      taps: Optional[dict] = None) -> Tensor:
-    """VisualCLAModel.forward with image_at_head=False (the production path,
-    modeling_utils.py:134): returns logits [B, T, V] in `dtype`."""
+                      taps: Optional[dict] = None, image_at_head: bool = False, labels: Optional[Tensor] = None,
+                      cache: Optional[List] = None, past_len: int = 0):
+    """VisualCLAModel.forward (modeling_visualcla.py:264-330): returns logits [B, T', V] in `dtype`, or
+    (logits, loss) when `labels` is given.
+
+    image_at_head=False (the production setting, modeling_utils.py:134): image embeds overwrite the <img_token> slots
+    (:293-305), mask and labels pass through.  image_at_head=True (:290-291, :308-310, :313-315): embeds =
+    emb[:, :2] ++ image ++ emb[:, 2:], mask = ones[B, Q] ++ mask (image columns FIRST), labels = labels[:, :1] ++ Q x -100 ++
+    labels[:, 1:] -- the reference inserts the ignore labels one position EARLIER than the image embeds; restated as written.
+    `cache` (a list of per-layer (k, v) or None entries, filled in place) + `past_len` = the past_key_values pass-through
+    (:321-328): a later call with the next ids and the full-length mask continues the sequence."""
     W = _cast_weights(W, dtype)
     img = None
     if pixel_values is not None:
         img = image_embeds(pixel_values.to(dtype), W, cfg, taps)
-    x = embed_and_splice(input_ids, img, W, cfg, dtype)
+    if img is not None and image_at_head:
+        emb = W["text_model.model.embed_tokens.weight"].to(dtype)[input_ids]
+        x = torch.cat([emb[:, :2], img.to(dtype), emb[:, 2:]], dim=1)
+        B, Q = img.shape[:2]
+        if attention_mask is not None:
+            attention_mask = torch.cat([torch.ones(B, Q, dtype=attention_mask.dtype), attention_mask], dim=1)
+        if labels is not None:
+            labels = torch.cat([labels[:, :1], torch.full((B, Q), -100, dtype=labels.dtype), labels[:, 1:]], dim=1)
+    else:
+        x = embed_and_splice(input_ids, img, W, cfg, dtype)
     if taps is not None:
         taps["spliced_embeds"] = x
-    h = llama_forward(x, W, cfg.text, attention_mask, None, 0, taps)
+    h = llama_forward(x, W, cfg.text, attention_mask, cache, past_len, taps)
     if taps is not None:
         taps["final_norm"] = h
     logits = lm_head(h, W)
     if taps is not None:
         taps["logits"] = logits
+    if labels is not None:
+        return logits, causal_lm_loss(logits, labels)
     return logits
 
 
 def visualcla_generate(input_ids: Tensor, pixel_values: Optional[Tensor], attention_mask: Tensor,
                        W: Dict[str, Tensor], cfg: OracleCfg, max_new_tokens: int,
                        eos_token_id: Optional[int] = None, dtype=torch.float32,
-                       return_logits: bool = False, select_fn=None):
+                       return_logits: bool = False, select_fn=None, image_at_head: bool = False):
     """`select_fn(logits [B, V], generated [B, step]) -> next ids [B]` replaces the argmax (sampling oracle, next row N2).
 
     VisualCLAModel.generate, greedy (do_sample=False): prefill over the spliced embeds with a
@@ -559,10 +589,15 @@ def visualcla_generate(input_ids: Tensor, pixel_values: Optional[Tensor], attent
     tokens only, as HF does when called with inputs_embeds (modeling_utils.py:173-174)."""
     W = _cast_weights(W, dtype)
     img = image_embeds(pixel_values.to(dtype), W, cfg) if pixel_values is not None else None
-    x = embed_and_splice(input_ids, img, W, cfg, dtype)
+    mask = attention_mask.clone()
+    if img is not None and image_at_head:           # modeling_visualcla.py:356, :373-375
+        emb = W["text_model.model.embed_tokens.weight"].to(dtype)[input_ids]
+        x = torch.cat([emb[:, :2], img.to(dtype), emb[:, 2:]], dim=1)
+        mask = torch.cat([torch.ones(img.shape[0], img.shape[1], dtype=mask.dtype), mask], dim=1)
+    else:
+        x = embed_and_splice(input_ids, img, W, cfg, dtype, need_img_token=False)
     B, T, _ = x.shape
     cache: List = [None] * cfg.text.num_hidden_layers
-    mask = attention_mask.clone()
     h = llama_forward(x, W, cfg.text, mask, cache, 0)
     logits = lm_head(h[:, -1:, :], W)[:, 0].float()
     out, all_logits = [], [logits]

@@ -89,3 +89,100 @@ def test_position_embedding_extension():
     assert out["vision_model.vision_model.embeddings.position_ids"].shape == (1, 37)
     same = extend_position_embedding({k: v.clone() for k, v in sd.items()}, 14, 6 * 14)   # idempotent at the target size
     assert torch.equal(same["vision_model.vision_model.embeddings.position_embedding.weight"], new)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Edge cases of the reference's forward / generate (tests/golden/ref_edge_cases.npz, written by oracle/make_golden.py:edge_cases
+# from the reference's own VisualCLAModel): the oracle's behaviour on these inputs is pinned here, and the GPU tests that lean on
+# the oracle for the same situations (tests/test_gpu_model.py) also compare with these fixtures directly.
+# ---------------------------------------------------------------------------------------------------------------------
+def _edge(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "ref_edge_cases.npz"))
+    pre = case + "__"
+    return {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def _tiny_inputs(T=34, npre=5):
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 2, T, n_prefix=npre)
+    return cfg, W, px, ids, mask
+
+
+@pytest.mark.parametrize("cname", ["tiny", "small"])
+def test_edge_left_padded_batch(cname, golden_dir):
+    """modeling_visualcla.py:307-312: the text mask reaches HF unchanged; row 1 is left-padded"""
+    e = _edge(golden_dir, f"leftpad_{cname}")
+    T, npre, n_new = (int(x) for x in e["meta"])
+    cfg = {"tiny": O.cfg_tiny, "small": O.cfg_small}[cname]()
+    W = O.make_weights(cfg, seed=0)
+    px, _, _ = O.make_inputs(cfg, 2, T, n_prefix=npre)
+    ids, mask = e["input_ids"], e["attention_mask"]
+    assert int((mask == 0).sum()) > 0
+    got = O.visualcla_forward(ids, px, mask, W, cfg)
+    valid = mask.bool()
+    assert (got[valid] - e["logits"][valid]).abs().max().item() <= 2e-5      # padded rows' logits are don't-care (HF: uniform attention)
+    toks = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=n_new)
+    assert torch.equal(toks, e["generated"])
+
+
+def test_edge_text_only_forward(golden_dir):
+    """modeling_visualcla.py:317-319 (pixel_values=None)"""
+    e = _edge(golden_dir, "textonly")
+    cfg, W, _, _, _ = _tiny_inputs()
+    ids, mask = e["input_ids"], e["attention_mask"]
+    assert torch.allclose(O.visualcla_forward(ids, None, torch.ones_like(ids), W, cfg), e["logits_full_mask"], atol=2e-5)
+    got = O.visualcla_forward(ids, None, mask, W, cfg)
+    assert (got[mask.bool()] - e["logits"][mask.bool()]).abs().max().item() <= 2e-5
+
+
+def test_edge_labels_and_loss_image_in_slots(golden_dir):
+    """labels pass through to LlamaForCausalLM (modeling_visualcla.py:321-328) -> .loss"""
+    e = _edge(golden_dir, "slot_labels")
+    cfg, W, px, ids, mask = _tiny_inputs()
+    assert torch.equal(ids, e["input_ids"])
+    logits, loss = O.visualcla_forward(ids, px, mask, W, cfg, labels=e["labels"])
+    assert torch.allclose(logits, e["logits"], atol=2e-5)
+    assert abs(float(loss) - float(e["loss"][0])) <= 1e-5, (float(loss), float(e["loss"][0]))
+
+
+def test_edge_image_at_head_with_labels(golden_dir):
+    """image_at_head=True (modeling_visualcla.py:290-291, 308-310, 313-315), incl. the reference's label placement (ignore labels
+    inserted after position 0 while the image embeds go in after position 1) -- logits, loss and greedy ids"""
+    e = _edge(golden_dir, "head_labels")
+    cfg, W, px, _, _ = _tiny_inputs()
+    ids, mask, labels = e["input_ids"], e["attention_mask"], e["labels"]
+    logits, loss = O.visualcla_forward(ids, px, mask, W, cfg, image_at_head=True, labels=labels)
+    assert logits.shape == e["logits"].shape and torch.allclose(logits, e["logits"], atol=2e-5)
+    assert abs(float(loss) - float(e["loss"][0])) <= 1e-5, (float(loss), float(e["loss"][0]))
+    # the placement matters: shifting the ignore labels to where the image embeds really are gives another loss
+    Q = cfg.resampler.num_query_tokens
+    aligned = torch.cat([labels[:, :2], torch.full((2, Q), -100), labels[:, 2:]], dim=1)
+    assert abs(float(O.causal_lm_loss(logits, aligned)) - float(e["loss"][0])) > 1e-4
+    toks = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=e["generated"].shape[1], image_at_head=True)
+    assert torch.equal(toks, e["generated"])
+
+
+def test_edge_past_key_values_pass_through(golden_dir):
+    """use_cache=True, then single-token forwards on the returned cache (modeling_visualcla.py:321-328)"""
+    e = _edge(golden_dir, "cache")
+    cfg, W, px, ids, mask = _tiny_inputs()
+    assert torch.equal(ids, e["input_ids"])
+    cache = [None] * cfg.text.num_hidden_layers
+    T = ids.shape[1]
+    p = O.visualcla_forward(ids[:, :-2], px, mask[:, :-2], W, cfg, cache=cache)
+    s1 = O.visualcla_forward(ids[:, -2:-1], None, mask[:, :-1], W, cfg, cache=cache, past_len=T - 2)
+    s2 = O.visualcla_forward(ids[:, -1:], None, mask, W, cfg, cache=cache, past_len=T - 1)
+    for got, key in ((p, "prompt_logits"), (s1, "step1_logits"), (s2, "step2_logits")):
+        assert got.shape == e[key].shape and torch.allclose(got, e[key], atol=2e-5), key
+
+
+def test_edge_row_without_an_image_slot(golden_dir):
+    """a row with no <img> keeps its text embeds although pixel_values holds an image for it (modeling_visualcla.py:297-299 / :363-365)"""
+    e = _edge(golden_dir, "mixed_rows")
+    cfg, W, px, _, _ = _tiny_inputs()
+    ids, mask = e["input_ids"], e["attention_mask"]
+    assert not bool((ids[1] == cfg.img_start_token_id).any())
+    assert torch.allclose(O.visualcla_forward(ids, px, mask, W, cfg), e["logits"], atol=2e-5)
+    toks = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=e["generated"].shape[1])
+    assert torch.equal(toks, e["generated"])
