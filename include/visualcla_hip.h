@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define VCLA_ABI_VERSION 2
+#define VCLA_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -355,8 +355,9 @@ size_t vcla_llama_workspace_bytes(const vcla_ctx* ctx, int B, int T);
 size_t vcla_kv_cache_bytes(const vcla_ctx* ctx, int B, int ctx_max);
 
 /* pixel_values [B, C, H, W] (act dtype) -> image_embeds [B, Q, t_hidden].
-   Optional taps (act dtype, may be NULL): vit_tap [v_layers + 1][B * N * v_hidden]
-   (post-LN output last), res_tap [r_layers][B * Q * r_hidden]. */
+   Optional taps (act dtype, may be NULL): vit_tap [v_layers + 2][B * N * v_hidden]
+   (entry v_layers = post-LN output, entry v_layers + 1 = the embedding stage: patch + class + position
+   embeddings after pre_layrnorm; ABI v3 -- v2 had v_layers + 1 entries), res_tap [r_layers][B * Q * r_hidden]. */
 int vcla_vision_forward(vcla_ctx* ctx, const void* pixel_values, void* image_embeds, int B, void* ws,
                         size_t ws_bytes, void* vit_tap, void* res_tap, void* stream);
 

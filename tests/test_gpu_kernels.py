@@ -620,6 +620,51 @@ def test_rope_kv_append_fp8_cache(lib):
     assert int((kc_d[:, :, T:] != 0x55).sum()) == 0 and int((vc_d[:, :, T:] != 0x55).sum()) == 0
 
 
+def test_fp8_cache_writers_saturate(lib):
+    """|k| or |v| beyond e4m3's 448: v_cvt_pk_fp8_f32 does not clamp (the byte would be NaN and poison every later step of that
+    (sequence, head)); the cache writers saturate first -- prefill append and decode append both store the e4m3 bytes of the value
+    clamped to +-448, and the decode step's own attention output stays finite"""
+    from visualcla.weights import rope_tables
+    B, T, H, d, ctx = 2, 4, 2, 128, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = bf16r(torch.randn(B, T, 3, H, d, generator=g))
+    qkv[0, 1, 1, 0, 3], qkv[1, 2, 1, 1, 70] = 1000.0, -3000.0           # keys (|.| survives the rotation: > 448 after RoPE too)
+    qkv[0, 0, 2, 1, 5], qkv[1, 3, 2, 0, 127] = 2048.0, -600.0           # values
+    cos, sin = rope_tables(256, d, 10000.0)
+    c, s = O.llama_rope_tables(torch.arange(T), d, 10000.0, torch.float32)
+    kr = bf16r(O.apply_rope(qkv[:, :, 1].permute(0, 2, 1, 3), bf16r(c), bf16r(s)))
+    assert float(kr.abs().max()) > 448
+    sat = lambda t: _fp8rt(t.clamp(-448.0, 448.0))[1]
+    qkv_d = qkv.reshape(B * T, 3 * H * d).to(DEV, torch.bfloat16).contiguous()
+    kc_d = torch.zeros(B, H, ctx, d, dtype=torch.uint8, device=DEV)
+    vc_d = torch.zeros(B, H, ctx, d, dtype=torch.uint8, device=DEV)
+    L = lib.load()
+    cos_d, sin_d = cos.to(DEV), sin.to(DEV)
+    lib.check(L.vcla_rope_kv_append(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(), B, T, H, d, ctx, 0,
+                                    None, lib.dtype_code(torch.bfloat16) | KV_FP8, lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(kc_d[:, :, :T].cpu(), sat(kr)) and torch.equal(vc_d[:, :, :T].cpu(), sat(qkv[:, :, 2].permute(0, 2, 1, 3)))
+    assert not bool(torch.isnan(kc_d.view(torch.float8_e4m3fn).float()).any()) and not bool(torch.isnan(vc_d.view(torch.float8_e4m3fn).float()).any())
+    # decode append at position T with an outlier in the new token's key and value
+    step = bf16r(torch.randn(B, 3, H, d, generator=g))
+    step[0, 1, 0, 9], step[1, 2, 1, 64] = -900.0, 5000.0
+    c1, s1 = O.llama_rope_tables(torch.tensor([T]), d, 10000.0, torch.float32)
+    kn = bf16r(O.apply_rope(step[:, 1][:, :, None, :], bf16r(c1), bf16r(s1)))
+    step_d = step.reshape(B, 3 * H * d).to(DEV, torch.bfloat16).contiguous()
+    out = torch.empty(B, H * d, dtype=torch.bfloat16, device=DEV)
+    lib.check(L.vcla_attn_decode_fused(step_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), cos_d.data_ptr(), sin_d.data_ptr(), out.data_ptr(), B, H, d, ctx,
+                                       T, None, None, 0, 1 / math.sqrt(d), lib.dtype_code(torch.bfloat16) | KV_FP8, 0, lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(kc_d[:, :, T].cpu(), sat(kn[:, :, 0])) and torch.equal(vc_d[:, :, T].cpu(), sat(step[:, 2]))
+    assert bool(torch.isfinite(out.float()).all())
+    # and the step computed the function of the SATURATED cache (the new token enters its own softmax as the stored byte)
+    K = torch.cat([kc_d[:, :, :T].cpu().view(torch.float8_e4m3fn).float(), sat(kn).view(torch.float8_e4m3fn).float()], dim=2)
+    V = torch.cat([vc_d[:, :, :T].cpu().view(torch.float8_e4m3fn).float(), sat(step[:, 2][:, :, None, :]).view(torch.float8_e4m3fn).float()], dim=2)
+    q = bf16r(O.apply_rope(step[:, 0][:, :, None, :], bf16r(c1), bf16r(s1)))
+    ref = _attn_ref(q, K, V, 1 / math.sqrt(d), True, torch.ones(B, ctx, dtype=torch.int32))
+    _cmp("attn_decode_fused_fp8kv_saturated", out.view(B, 1, H * d), ref, atol=4.0, rtol=2e-2)
+
+
 # ------------------------------------------------------------------ MFMA flash attention (bf16)
 @pytest.mark.parametrize("B,H,Tq,Tk,D,causal", [
     (2, 3, 257, 257, 64, False), (1, 2, 64, 321, 64, False), (2, 4, 48, 48, 128, True), (1, 2, 130, 130, 128, True),

@@ -46,7 +46,7 @@ def test_fp32_mode_matches_reference_golden(name, golden_dir):
     torch.cuda.synchronize()
     worst = 0.0
     for k in g.files:
-        if k.startswith("_") or k in ("generated", "vit_embed"):
+        if k.startswith("_") or k == "generated":
             continue
         ref = torch.from_numpy(g[k])
         got = taps[k].float().cpu().reshape(ref.shape)
@@ -68,7 +68,7 @@ def test_bf16_mode_vs_reference_golden(name, golden_dir):
     taps = {}
     out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), taps=taps)
     for k in g.files:
-        if k.startswith("_") or k in ("generated", "vit_embed"):
+        if k.startswith("_") or k == "generated":
             continue
         ref = torch.from_numpy(g[k])
         got = taps[k].float().cpu().reshape(ref.shape)
@@ -166,6 +166,124 @@ def test_image_at_head_mode():
     h = O.llama_forward(x, W, cfg.text, torch.ones(2, 10 + Q, dtype=torch.int64))
     ref = O.lm_head(h, W)
     assert out.shape == ref.shape and (out - ref).abs().max().item() <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own outputs on the edge cases of forward / generate (tests/golden/ref_edge_cases.npz, oracle/make_golden.py:
+# edge_cases): left-padded batches, text-only prompts, labels -> .loss in both image placements, past_key_values, a row without
+# an image slot.  fp32 mode: logits within 1e-3 (north_star), loss within 1e-4, greedy ids identical; bf16 mode: the stated bf16 bounds.
+# ---------------------------------------------------------------------------------------------------------------------
+def _edge(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "ref_edge_cases.npz"))
+    pre = case + "__"
+    return {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def _edge_model(dtype, cname="tiny", T=34, npre=5):
+    cfg = {"tiny": O.cfg_tiny, "small": O.cfg_small}[cname]()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 2, T, n_prefix=npre)
+    return cfg, make_hip_model(cfg, W, dtype), px, ids, mask
+
+
+def _logit_bounds(dtype):
+    return (1e-3, 1e-3) if dtype == torch.float32 else (6e-2, 1e-2)       # (max, mean) abs error vs the fp32 reference
+
+
+def _check_logits(tag, got, ref, dtype, valid=None):
+    got, ref = got.float().cpu(), ref.float()
+    assert got.shape == ref.shape, (tag, got.shape, ref.shape)
+    err = (got - ref).abs()
+    if valid is not None:
+        err = err[valid]
+    mx, mean = _logit_bounds(dtype)
+    _report(f"edge {tag} [{dtype}]: logits max_abs_err={err.max().item():.3e} mean={err.mean().item():.3e}")
+    assert err.max().item() <= mx and err.mean().item() <= mean, (tag, err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cname", ["tiny", "small"])
+def test_edge_left_padded_batch_matches_reference(cname, dtype, golden_dir):
+    e = _edge(golden_dir, f"leftpad_{cname}")
+    T, npre, n_new = (int(x) for x in e["meta"])
+    cfg, m, px, _, _ = _edge_model(dtype, cname, T, npre)
+    ids, mask = e["input_ids"], e["attention_mask"]
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda())
+    _check_logits(f"leftpad_{cname}", out.logits, e["logits"], dtype, valid=mask.bool())
+    if dtype == torch.float32:          # bf16: ids may legitimately flip at small top-2 margins; the logits above are the check
+        toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=n_new, do_sample=False,
+                          eos_token_id=None).cpu()
+        assert torch.equal(toks, e["generated"]), (toks, e["generated"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_text_only_forward_matches_reference(dtype, golden_dir):
+    e = _edge(golden_dir, "textonly")
+    cfg, m, _, _, _ = _edge_model(dtype)
+    ids, mask = e["input_ids"], e["attention_mask"]
+    out = m.forward(input_ids=ids.cuda(), attention_mask=torch.ones_like(ids).cuda())
+    _check_logits("textonly(full mask)", out.logits, e["logits_full_mask"], dtype)
+    out = m.forward(input_ids=ids.cuda(), attention_mask=mask.cuda())
+    _check_logits("textonly(left pad)", out.logits, e["logits"], dtype, valid=mask.bool())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_loss_with_the_image_in_its_slots_matches_reference(dtype, golden_dir):
+    """forward(labels=...) -> .loss (modeling_visualcla.py:321-328 -> LlamaForCausalLM's shifted cross-entropy)"""
+    e = _edge(golden_dir, "slot_labels")
+    cfg, m, px, ids, mask = _edge_model(dtype)
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), labels=e["labels"].cuda())
+    _check_logits("slot_labels", out.logits, e["logits"], dtype)
+    d = abs(float(out.loss) - float(e["loss"][0]))
+    _report(f"edge slot_labels [{dtype}]: loss {float(out.loss):.6f} vs reference {float(e['loss'][0]):.6f}")
+    assert d <= (1e-4 if dtype == torch.float32 else 1e-2), d
+    tup = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), labels=e["labels"].cuda(), return_dict=False)
+    assert len(tup) == 2 and abs(float(tup[0]) - float(out.loss)) == 0.0        # (loss, logits) as HF's tuple output
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_image_at_head_logits_loss_and_ids_match_reference(dtype, golden_dir):
+    """image_at_head=True with labels: the reference places the Q ignore-labels after position 0 while the image embeds go in after
+    position 1 (modeling_visualcla.py:291 vs :315); the loss fixture has labels[:, 1] supervised, so a 'corrected' placement fails here"""
+    e = _edge(golden_dir, "head_labels")
+    cfg, m, px, _, _ = _edge_model(dtype)
+    m.image_at_head = True
+    ids, mask, labels = e["input_ids"], e["attention_mask"], e["labels"]
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
+    _check_logits("head_labels", out.logits, e["logits"], dtype)
+    d = abs(float(out.loss) - float(e["loss"][0]))
+    _report(f"edge head_labels [{dtype}]: loss {float(out.loss):.6f} vs reference {float(e['loss'][0]):.6f}")
+    assert d <= (1e-4 if dtype == torch.float32 else 1e-2), d
+    if dtype == torch.float32:
+        toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=e["generated"].shape[1],
+                          do_sample=False, eos_token_id=None).cpu()
+        assert torch.equal(toks, e["generated"]), (toks, e["generated"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_past_key_values_pass_through_matches_reference(dtype, golden_dir):
+    e = _edge(golden_dir, "cache")
+    cfg, m, px, ids, mask = _edge_model(dtype)
+    first = m.forward(input_ids=ids[:, :-2].cuda(), pixel_values=px.cuda(), attention_mask=mask[:, :-2].cuda(), use_cache=True)
+    _check_logits("cache(prompt)", first.logits, e["prompt_logits"], dtype)
+    s1 = m.forward(input_ids=ids[:, -2:-1].cuda(), attention_mask=mask[:, :-1].cuda(), past_key_values=first.past_key_values, use_cache=True)
+    _check_logits("cache(step 1)", s1.logits, e["step1_logits"], dtype)
+    s2 = m.forward(input_ids=ids[:, -1:].cuda(), attention_mask=mask.cuda(), past_key_values=s1.past_key_values, use_cache=True)
+    _check_logits("cache(step 2)", s2.logits, e["step2_logits"], dtype)
+    assert s2.past_key_values.get_seq_length() == ids.shape[1]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_row_without_an_image_slot_matches_reference(dtype, golden_dir):
+    e = _edge(golden_dir, "mixed_rows")
+    cfg, m, px, _, _ = _edge_model(dtype)
+    ids, mask = e["input_ids"], e["attention_mask"]
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda())
+    _check_logits("mixed_rows", out.logits, e["logits"], dtype)
+    if dtype == torch.float32:
+        toks = m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=e["generated"].shape[1],
+                          do_sample=False, eos_token_id=None).cpu()
+        assert torch.equal(toks, e["generated"]), (toks, e["generated"])
 
 
 def test_masks_with_interior_zeros_are_refused():
@@ -549,6 +667,61 @@ def test_7b_prefill_and_decode_logits_match_oracle(model_7b):
             e_ = (seen[s_] - refs[s_]).abs()
             _report(f"7B B={nb} {'prefill' if s_ == 0 else f'decode step {s_}'} logits vs fp32 oracle: max {e_.max().item():.3e} mean {e_.mean().item():.3e}")
             assert e_.max().item() <= B7_LOGIT_MAX and e_.mean().item() <= B7_LOGIT_MEAN, (nb, s_, e_.max().item())
+
+
+def test_7b_fp32_mode_logits_are_within_1e3_of_the_oracle(model_7b):
+    """north_star's tolerance AT THE BASELINE SHAPE (configs[1] geometry: VisualCLA-7B, B = 1, T = 128 with the 64 image slots):
+    the fp32 activation mode of the HIP path -- same kernels' arithmetic order, fp32 storage between them, the same bf16-rounded
+    weights as the oracle -- must give every stage tap and the full-sequence logits within 1e-3 ABS of the fp32 oracle, and so must
+    two single-token forwards on the returned cache.  If a stage ever exceeds the bound the report names the first one."""
+    import visualcla
+    m16, ocfg = model_7b
+    _oracle_threads()
+    W = _w7(m16)
+    B, T = 1, 128
+    px, ids, mask = O.make_inputs(ocfg, B, T)
+    m = visualcla.VisualCLAModel.from_state_dict(m16.config, W, device="cuda:0", torch_dtype=torch.float32)
+    m.tokenizer, m.image_at_head = stub_tokenizer(ocfg), False
+    try:
+        ref_t = {}
+        cache = [None] * ocfg.text.num_hidden_layers
+        with torch.no_grad():
+            ref = O.visualcla_forward(ids, px, mask, W, ocfg, taps=ref_t, cache=cache)
+        taps = {}
+        out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), use_cache=True, taps=taps)
+        torch.cuda.synchronize()
+        first_bad, worst = None, 0.0
+        order = (["vit_embed"] + [f"vit_layer{i}" for i in range(ocfg.vision.num_hidden_layers)] + ["vit_post_ln"] +
+                 [f"resampler_layer{i}" for i in range(ocfg.resampler.num_hidden_layers)] + ["image_embeds", "spliced_embeds"] +
+                 [f"llama_layer{i}" for i in range(ocfg.text.num_hidden_layers)] + ["final_norm", "logits"])
+        for k in order:
+            r = ref_t[k].float()
+            e = (taps[k].float().cpu().reshape(r.shape) - r).abs().max().item()
+            worst = max(worst, e)
+            if k in ("vit_embed", "vit_layer23", "vit_post_ln", "resampler_layer5", "image_embeds", "llama_layer0", "llama_layer15", "llama_layer31", "final_norm", "logits"):
+                _report(f"7B fp32 mode vs fp32 oracle {k}: max_abs_err={e:.3e} (ref absmax {r.abs().max().item():.2e})")
+            if e > 1e-3 and first_bad is None:
+                first_bad = (k, e)
+        e_log = (out.logits.float().cpu() - ref).abs()
+        _report(f"7B fp32 mode [B={B}, T={T}]: logits max_abs_err={e_log.max().item():.3e} mean={e_log.mean().item():.3e} (ref std {ref.std().item():.3f}); "
+                f"worst stage {worst:.3e}; first stage over 1e-3: {first_bad}")
+        assert first_bad is None and e_log.max().item() <= 1e-3, (first_bad, e_log.max().item())
+        assert torch.equal(out.logits.argmax(-1).cpu(), ref.argmax(-1))
+        # two decode steps on the cache (single-token forward: the fp32 GEMV path), teacher-forced with the oracle's greedy ids
+        kv, past = out.past_key_values, T
+        nxt = ref[:, -1].argmax(-1)
+        for step in range(2):
+            full_mask = torch.ones(B, past + 1, dtype=torch.int64)
+            with torch.no_grad():
+                r = O.visualcla_forward(nxt[:, None], None, full_mask, W, ocfg, cache=cache, past_len=past)
+            o = m.forward(input_ids=nxt[:, None].cuda(), attention_mask=full_mask.cuda(), past_key_values=kv, use_cache=True)
+            e = (o.logits.float().cpu() - r).abs().max().item()
+            _report(f"7B fp32 mode decode step {step + 1} (context {past + 1}): logits max_abs_err={e:.3e}")
+            assert e <= 1e-3, (step, e)
+            kv, past, nxt = o.past_key_values, past + 1, r[:, -1].argmax(-1)
+    finally:
+        del m
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

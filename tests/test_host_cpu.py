@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vcla_version() == 2
+    assert lib.vcla_version() == 3
 
 
 def test_no_gpu_fails_loudly():

@@ -353,9 +353,9 @@ __device__ __forceinline__ void fp8x16_to_f32(const u32x4_t& t, float* v) {
     }
 }
 // e4m3 rounding of one value: the byte, and the value it decodes to
-__device__ __forceinline__ unsigned char f32_to_fp8(float x) { return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff); }
+__device__ __forceinline__ unsigned char f32_to_fp8(float x) { return (unsigned char)(VCLA_CVT_PK_FP8_SAT(x, x, 0, false) & 0xff); }
 __device__ __forceinline__ float fp8_round(float x) {
-    const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false), false);
+    const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(VCLA_CVT_PK_FP8_SAT(x, x, 0, false), false);
     return r.x;
 }
 

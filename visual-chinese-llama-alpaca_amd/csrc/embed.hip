@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, void*
             const float r0 = Act<T>::rnd(k0 * c - k1 * s), r1 = Act<T>::rnd(k1 * c + k0 * s);
             Act<T>::st(k + o, r0);
             Act<T>::st(k + o + half, r1);
-            const unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, 0, false);
+            const unsigned pk = (unsigned)VCLA_CVT_PK_FP8_SAT(r0, r1, 0, false);
             kc8[ko] = (unsigned char)(pk & 0xff);
             kc8[ko + half] = (unsigned char)((pk >> 8) & 0xff);
         } else {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, void*
     if constexpr (KV8) {
         for (int idx = threadIdx.x * 2; idx < HD; idx += 512) {     // two adjacent values per thread: one 2-byte store (d is even)
             const int h = idx / d, i = idx % d;
-            const unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(Act<T>::ld(v + idx), Act<T>::ld(v + idx + 1), 0, false);
+            const unsigned pk = (unsigned)VCLA_CVT_PK_FP8_SAT(Act<T>::ld(v + idx), Act<T>::ld(v + idx + 1), 0, false);
             *reinterpret_cast<unsigned short*>(vc8 + (((int64_t)b * H + h) * ctx_max + pos) * d + i) = (unsigned short)(pk & 0xffff);
         }
     } else {
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(bf16_t* __restrict__ q
             unsigned char* kc8 = (unsigned char*)kc_;
             float f[8];
             bf8_to_f32(lo, f);
-            unsigned w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-            unsigned w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            unsigned w0 = VCLA_CVT_PK_FP8_SAT(f[0], f[1], 0, false); w0 = VCLA_CVT_PK_FP8_SAT(f[2], f[3], w0, true);
+            unsigned w1 = VCLA_CVT_PK_FP8_SAT(f[4], f[5], 0, false); w1 = VCLA_CVT_PK_FP8_SAT(f[6], f[7], w1, true);
             *reinterpret_cast<uint2*>(kc8 + ko) = make_uint2(w0, w1);
             bf8_to_f32(hi, f);
-            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            w0 = VCLA_CVT_PK_FP8_SAT(f[0], f[1], 0, false); w0 = VCLA_CVT_PK_FP8_SAT(f[2], f[3], w0, true);
+            w1 = VCLA_CVT_PK_FP8_SAT(f[4], f[5], 0, false); w1 = VCLA_CVT_PK_FP8_SAT(f[6], f[7], w1, true);
             *reinterpret_cast<uint2*>(kc8 + ko + half) = make_uint2(w0, w1);
         } else {
             bf16_t* kc = (bf16_t*)kc_;
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(bf16_t* __restrict__ q
         if constexpr (KV8) {
             float f[8];
             bf8_to_f32(vv, f);
-            unsigned w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-            unsigned w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            unsigned w0 = VCLA_CVT_PK_FP8_SAT(f[0], f[1], 0, false); w0 = VCLA_CVT_PK_FP8_SAT(f[2], f[3], w0, true);
+            unsigned w1 = VCLA_CVT_PK_FP8_SAT(f[4], f[5], 0, false); w1 = VCLA_CVT_PK_FP8_SAT(f[6], f[7], w1, true);
             *reinterpret_cast<uint2*>((unsigned char*)vc_ + vo) = make_uint2(w0, w1);
         } else {
             *reinterpret_cast<uint4*>((bf16_t*)vc_ + vo) = vv;

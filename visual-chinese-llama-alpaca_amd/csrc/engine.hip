@@ -179,7 +179,7 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
                      c.t_hidden % 64 == 0 && c.t_inter % 64 == 0, VCLA_ERR_BAD_SHAPE,
                  "ctx_create: hidden / intermediate sizes must be multiples of 64");
     VCLA_REQUIRE(c.t_inter % 16 == 0, VCLA_ERR_BAD_SHAPE, "ctx_create: t_inter must be a multiple of 16 (SwiGLU packing)");
-    VCLA_REQUIRE(!c.t_kv_fp8 || (c.act_dtype == VCLA_BF16 && c.t_heads > 0 && c.t_hidden / c.t_heads >= 64), VCLA_ERR_BAD_ARG,
+    VCLA_REQUIRE(!c.t_kv_fp8 || (c.act_dtype == VCLA_BF16 && c.t_heads > 0 && (c.t_hidden / c.t_heads == 64 || c.t_hidden / c.t_heads == 128)), VCLA_ERR_BAD_ARG,
                  "ctx_create: t_kv_fp8 (e4m3 K/V cache) needs bf16 activations and a text head dim of 64 or 128");
     VCLA_REQUIRE(c.r_hidden == c.v_hidden, VCLA_ERR_BAD_SHAPE,
                  "ctx_create: resampler hidden (%d) must equal vision hidden (%d): latents are concatenated with image tokens",
@@ -198,12 +198,19 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
     return VCLA_OK;
 }
 
+// The cached graphs bake in weight pointers: registering a tensor (LoRA swap, adding fp8 copies) makes all of them stale.
+static void drop_graphs(vcla_ctx* ctx) {
+    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+    if (ctx->graph_exec_multi) { (void)hipGraphExecDestroy(ctx->graph_exec_multi); ctx->graph_exec_multi = nullptr; }
+    for (vcla_ctx::MacroGraph* g : {&ctx->vision_graph, &ctx->prefill_graph}) {
+        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        g->has_seen = 0;
+    }
+}
+
 extern "C" void vcla_ctx_destroy(vcla_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
-    if (ctx->graph_exec_multi) (void)hipGraphExecDestroy(ctx->graph_exec_multi);
-    if (ctx->vision_graph.exec) (void)hipGraphExecDestroy(ctx->vision_graph.exec);
-    if (ctx->prefill_graph.exec) (void)hipGraphExecDestroy(ctx->prefill_graph.exec);
+    drop_graphs(ctx);
     delete ctx;
 }
 
@@ -212,6 +219,7 @@ extern "C" int vcla_ctx_set_tensor(vcla_ctx* ctx, const char* name, const void* 
     VCLA_REQUIRE(vcla_aligned(ptr, 16), VCLA_ERR_BAD_ARG, "ctx_set_tensor: %s is not 16-byte aligned", name);
     ctx->tensors[name] = TensorRef{ptr, nbytes};
     ctx->finalized = false;
+    drop_graphs(ctx);
     return VCLA_OK;
 }
 
@@ -507,6 +515,11 @@ template <typename F>
 static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipStream_t s, F&& run) {
     static const int genv = getenv("VCLA_MACRO_GRAPH") ? atoi(getenv("VCLA_MACRO_GRAPH")) : 1;
     if (!genv || s == nullptr) return run(s);
+    // The caller is capturing on this stream itself (torch.cuda.graph, or its own hipGraph around this entry point): the launches
+    // belong in ITS graph -- replaying ours or opening a nested capture would both be wrong.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return run(s); }
+    if (cap != hipStreamCaptureStatusNone) return run(s);
     static const int dbg = getenv("VCLA_MACRO_GRAPH_DEBUG") ? atoi(getenv("VCLA_MACRO_GRAPH_DEBUG")) : 0;
     if (g.exec && memcmp(g.key, key, sizeof(g.key)) == 0) {
         VCLA_CHECK_HIP(hipGraphLaunch(g.exec, s));
@@ -523,16 +536,27 @@ static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipSt
     g.has_seen = 1;
     const int rc_eager = run(s);
     if (rc_eager || !(repeat || first)) return rc_eager;
+    // From here on the call has SUCCEEDED (the eager launches are issued): a capture that cannot be taken or instantiated only means
+    // "no cached graph" -- the next call runs eagerly again.
+    auto no_graph = [&](const char* what, hipError_t e) {
+        if (dbg) fprintf(stderr, "[vcla] macro graph %p: %s failed (%s), staying eager\n", (void*)&g, what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        return VCLA_OK;
+    };
     hipGraph_t graph = nullptr;
-    VCLA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return no_graph("hipStreamBeginCapture", e);
     const int rc = run(s);
-    const hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    e = hipStreamEndCapture(s, &graph);
+    if (rc || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return no_graph("capture", e);
+    }
     hipGraphExec_t exec = nullptr;
-    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) return vcla_fail(VCLA_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    if (e != hipSuccess) return no_graph("hipGraphInstantiate", e);
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     g.exec = exec;
     memcpy(g.key, key, sizeof(g.key));
@@ -571,6 +595,7 @@ static int vision_forward_impl(vcla_ctx* ctx, const void* pixel_values, void* im
     RUN(vcla_im2col(pixel_values, w.patches, B, c.v_channels, c.v_image, c.v_image, c.v_patch, ctx->k_pad, dt, s));
     RUN(gemm(ctx, s, w.patches, ctx->k_pad, ctx->vit_patch_w, nullptr, nullptr, 0, w.patch_emb, D, B * np, D, ctx->k_pad, VCLA_EPI_NONE));
     RUN(vcla_vit_assemble(w.patch_emb, ctx->vit_cls, ctx->vit_pos, ctx->vit_pre_g, ctx->vit_pre_b, w.x, B, np, D, c.v_eps, dt, s));
+    RUN(tap_copy(vit_tap, c.v_layers + 1, w.x, (size_t)M * D * e, s));   // embeddings + pre-LN (hf CLIPVisionTransformer: pre_layrnorm output)
 
     for (int l = 0; l < c.v_layers; ++l) {
         const VitLayer& L = ctx->vit[l];
@@ -766,6 +791,9 @@ extern "C" int vcla_llama_prefill(vcla_ctx* ctx, const void* inputs_embeds, int 
                  "llama_prefill: B=%d T=%d pos0=%d ctx_max=%d (max_pos %d)", B, T, pos0, ctx_max, c.t_max_pos);
     VCLA_REQUIRE(ws_bytes >= vcla_llama_workspace_bytes(ctx, B, T), VCLA_ERR_WORKSPACE, "llama_prefill: workspace %zu < %zu bytes",
                  ws_bytes, vcla_llama_workspace_bytes(ctx, B, T));
+    VCLA_REQUIRE(!(c.t_kv_fp8 && T > 1 && pos0 > 0), VCLA_ERR_BAD_ARG,
+                 "llama_prefill: with the fp8 K/V cache a multi-token forward must start at position 0 (it attends over its own bf16 "
+                 "rows; the 1-byte cache serves single-token steps) -- nothing was written");
     hipStream_t s = (hipStream_t)stream;
     if (layer_tap) return llama_prefill_impl(ctx, inputs_embeds, B, T, pos0, kv_cache, ctx_max, key_mask, logits, all_logits, ws, layer_tap, s);
     const void* const key[8] = {inputs_embeds, kv_cache, key_mask, logits, ws, (const void*)(((intptr_t)B << 32) | (uint32_t)T),
@@ -909,7 +937,9 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
         VCLA_CHECK_LAUNCH("post_select_kernel");
         return VCLA_OK;
     };
-    if (!use_graph || s == nullptr) {  // stream capture is illegal on the legacy default stream
+    hipStreamCaptureStatus outer = hipStreamCaptureStatusNone;   // the caller captures this stream itself: the steps belong in its graph
+    if (use_graph && s != nullptr && hipStreamIsCapturing(s, &outer) != hipSuccess) { (void)hipGetLastError(); outer = hipStreamCaptureStatusNone; }
+    if (!use_graph || s == nullptr || outer != hipStreamCaptureStatusNone) {  // stream capture is illegal on the legacy default stream
         for (int i = 0; i < n_steps; ++i) RUN(one_step(s));
         return VCLA_OK;
     }

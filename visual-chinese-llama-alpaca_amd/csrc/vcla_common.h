@@ -120,6 +120,12 @@ __device__ __forceinline__ void bf8_to_f32(const uint4& t, float* v) {
     v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
 }
 
+// fp32 pair -> two OCP e4m3fn bytes, SATURATING: v_cvt_pk_fp8_f32 does not clamp (|x| > 448 would encode as NaN, and one NaN byte in
+// the K/V cache poisons every later step of that (sequence, head)), so the operands go through v_med3_f32 first -- the same clamp
+// quant_fp8_rows applies to the activation rows
+#define VCLA_CVT_PK_FP8_SAT(a, b, old, hi)                                                                    \
+    __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f((a), 448.0f, -448.0f), __builtin_amdgcn_fmed3f((b), 448.0f, -448.0f), (old), (hi))
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

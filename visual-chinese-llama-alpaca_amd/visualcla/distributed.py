@@ -20,12 +20,17 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_tokens(tokens: torch.Tensor, n_total: Optional[int] = None, n_cols: Optional[int] = None, pad_id: int = 0) -> torch.Tensor:
+def gather_tokens(tokens: torch.Tensor, n_total: Optional[int] = None, n_cols: Optional[int] = None, pad_id: int = 0,
+                  force_collective: bool = False) -> torch.Tensor:
     """All-gather [b_rank, n] token ids from every rank into [n_total, n_cols] (rank order = request order) with ONE collective.
     The shard sizes follow from `shard_range(n_total, rank, world)` and every shard is padded to ceil(n_total / world) rows x
     `n_cols` columns (= max_new_tokens; early EOS leaves pad_id behind), so nothing has to be exchanged up front and nothing
-    synchronises the host.  Without n_total / n_cols (ragged callers) the shapes are exchanged first: two collectives."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    synchronises the host.  Without n_total / n_cols (ragged callers) the shapes are exchanged first: two collectives.
+    A world of one returns its own shard without touching the backend unless `force_collective` is set (the 1-GPU check that RCCL
+    initialises and moves int64 device tensors on this box: tests/test_gpu_distributed.py, bench.py --force-collective)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tokens
+    if dist.get_world_size() == 1 and not force_collective:
         return tokens
     world = dist.get_world_size()
     dev = tokens.device

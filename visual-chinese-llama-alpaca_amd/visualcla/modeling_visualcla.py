@@ -443,7 +443,7 @@ class VisualCLAModel:
         vit_tap = res_tap = None
         if taps is not None:
             N = (v["image_size"] // v["patch_size"]) ** 2 + 1
-            vit_tap = torch.empty(v["num_hidden_layers"] + 1, B, N, v["hidden_size"], dtype=self._dtype, device=self._device)
+            vit_tap = torch.empty(v["num_hidden_layers"] + 2, B, N, v["hidden_size"], dtype=self._dtype, device=self._device)
             res_tap = torch.empty(r["num_hidden_layers"], B, r["num_query_tokens"], r["hidden_size"], dtype=self._dtype, device=self._device)
         with torch.cuda.device(self._device):
             _lib.check(lib.vcla_vision_forward(self._ctx, px.data_ptr(), out.data_ptr(), B, ws.data_ptr(), ws.numel(),
@@ -451,7 +451,8 @@ class VisualCLAModel:
         if taps is not None:
             for i in range(v["num_hidden_layers"]):
                 taps[f"vit_layer{i}"] = vit_tap[i]
-            taps["vit_post_ln"] = vit_tap[-1]
+            taps["vit_post_ln"] = vit_tap[v["num_hidden_layers"]]
+            taps["vit_embed"] = vit_tap[v["num_hidden_layers"] + 1]
             for i in range(r["num_hidden_layers"]):
                 taps[f"resampler_layer{i}"] = res_tap[i]
             taps["image_embeds"] = out
