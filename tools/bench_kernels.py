@@ -291,6 +291,37 @@ def main():
             tp = timeit(lambda: _lib.rmsnorm_pack(xn, gam, 1e-6, out=pk), reps=50)
             print(f"M={M:3d} layer GEMMs: k8 (incl. reduce+norm launches) {tot['k8']*1e6:.1f} us | k9 {tot['k9']*1e6:.1f} us + 2 x rmsnorm_pack {tp*1e6:.1f} us"
                   f" = {(tot['k9'] + 2 * tp)*1e6:.1f} us ({404e6/(tot['k9'] + 2 * tp)/1e9:.0f} GB/s over 404 MB) || fp8: k8 {tot['k8q']*1e6:.1f} | k9 {tot['k9q']*1e6:.1f} us")
+    if "dec256" in which:
+        # decode batches of 65 - 256 rows: the row-major MFMA tile kernels through the product dispatch (what engine.hip's llama_layer
+        # issues), rotating over 4 weight buffers.  VCLA_MFMA128_S forces the K-slice count of the 128-tile kernel, VCLA_BENCH_FK the kernel.
+        print("== decode GEMMs at 65 <= M <= 256 (product dispatch); env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_")))
+        skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        fk = int(os.environ.get("VCLA_BENCH_FK", "0"))
+        for M in [int(x) for x in os.environ.get("VCLA_BENCH_MS", "256,192,128").split(",")]:
+            tot = 0.0
+            for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0), ("lm_head", 49958, 4096, 0)):
+                n_out = N // 2 if epi == 3 else N
+                a = rnd(M, K)
+                nb = 2 if tag == "lm_head" else 4
+                ws = [packw(N, K) for _ in range(nb)]
+                f32 = tag == "lm_head"
+                out = torch.empty(M, n_out, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+                res = rnd(M, n_out) if tag in ("o", "down") else None
+                gam = torch.ones(n_out, device=DEV)
+                hn = torch.empty(M, n_out, dtype=torch.bfloat16, device=DEV)
+                def run():
+                    for w in ws:
+                        if res is not None:
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, residual=res, force_kernel=fk, splitk_ws=skws, post_norm_gamma=gam, post_norm_eps=1e-6, post_norm_out=hn)
+                        else:
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, out_f32=f32, force_kernel=fk, splitk_ws=skws)
+                t = timeit(run, reps=10) / nb
+                by = ws[0].shape[0] * K * 2
+                print(f"M={M:3d} {tag:8s} N={N:6d} K={K:6d}  {t*1e6:7.1f} us  {by/t/1e9:6.0f} GB/s  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+                if tag != "lm_head":
+                    tot += t
+                del ws
+            print(f"M={M:3d} layer GEMMs (incl. reduce / norm launches): {tot*1e6:.1f} us")
     if "fp8mfma" in which:
         # BASELINE configs[4]: the prefill / ViT GEMM shapes on the bf16 MFMA kernel (4) vs fp8 x fp8 on the fp8 MFMA pipe (10)
         from visualcla.weights import quantize_fp8_rows

@@ -367,7 +367,7 @@ struct Bump {
     }
 };
 
-#define SPLITK_WS_BYTES ((size_t)32 << 20)   // fp32 scratch for the split-K panel GEMM (M <= 128)
+#define SPLITK_WS_BYTES ((size_t)64 << 20)   // fp32 scratch for the split-K panel GEMM (M <= 128)
 struct VisionWs {
     void *patches, *patch_emb, *x, *h, *qkv, *mlp;          // ViT
     void *lat, *q, *kv, *ao, *t, *h2, *ffn;                 // resampler

@@ -1112,10 +1112,15 @@ static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
     // Few tiles, long K (one image through the ViT: 24 - 96 tiles on 256 CUs, 16 - 64 serial K steps): split K so that ~256
     // workgroups run >= 4 K steps each; fp32 partial tiles + the panel kernel's reduce launch.  VCLA_MFMA128_SPLITK=0: off.
     static const int sk_env = getenv("VCLA_MFMA128_SPLITK") ? atoi(getenv("VCLA_MFMA128_SPLITK")) : 1;
+    // Round 4: also for 129 - 255 tiles (a 129 - 256-row decode batch: qkv = 192 tiles -> 2 slices) and with a post-norm request (o_proj /
+    // down_proj of those batches: 64 tiles ran 64 serial K steps on 64 CUs = 153 us; the wrapper's rmsnorm launch follows the reduce).
+    static const int s_force = getenv("VCLA_MFMA128_S") ? atoi(getenv("VCLA_MFMA128_S")) : 0;     // experiments: force the slice count
     int S = 1;
-    if (sk_env && a->splitk_ws && tiles <= 128 && nk >= 8 && !a->post_norm_gamma) {
+    if (sk_env && a->splitk_ws && tiles < 256 && nk >= 8) {
         const int n_pad = (a->N + 127) / 128 * 128;
         S = (256 + tiles - 1) / tiles;
+        if (tiles <= 64 && a->M > 128) S *= 2;       // one 128-row pair of tiles per 128 columns: fill both workgroup slots of every CU
+        if (s_force > 0) S = s_force;
         if (S > nk / 4) S = nk / 4;
         if (S > 8) S = 8;
         while (S > 1 && (size_t)S * a->M * n_pad * 4 > a->splitk_ws_bytes) --S;
@@ -1124,6 +1129,13 @@ static int launch_mfma(const vcla_gemm_args* a, hipStream_t s) {
         const int n_pad = (a->N + 127) / 128 * 128;
         gemm_mfma_kernel<EPI, OutT, true><<<dim3(tiles, S), 256, 0, s>>>(*a, tiles_m, tiles_n, S, n_pad, (float*)a->splitk_ws);
         VCLA_CHECK_LAUNCH("gemm_mfma_kernel");
+        if constexpr (EPI == VCLA_EPI_NONE && sizeof(OutT) == 2) {
+            if (S <= PN_MAX_SPLITK && a->post_norm_gamma && a->N <= PN_NORM_MAX) {   // reduce + residual + the NEXT RMSNorm of the row in one launch (as the panel kernel)
+                gemm_panel_reduce_norm_kernel<OutT><<<a->M, 1024, 0, s>>>(*a, S, n_pad, (const float*)a->splitk_ws);
+                VCLA_CHECK_LAUNCH("gemm_panel_reduce_norm_kernel");
+                return VCLA_POST_NORM_DONE;
+            }
+        }
         const int n_out = (EPI == VCLA_EPI_SWIGLU) ? a->N / 2 : a->N;
         const int64_t work = (int64_t)a->M * ((n_out + 3) / 4);
         gemm_panel_reduce_kernel<EPI, OutT><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(*a, S, n_pad, (const float*)a->splitk_ws);
