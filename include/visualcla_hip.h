@@ -224,7 +224,8 @@ typedef struct vcla_attn_args {
     int64_t key_mask_ld;
     const int32_t* tk_dev;  /* optional device scalar: effective Tk = *tk_dev + tk_dev_add (Tq = 1)  */
     int tk_dev_add;
-    int force_kernel;       /* 0 auto; 1 generic (fp32 math) kernel; 2 MFMA flash kernel            */
+    int force_kernel;       /* 0 auto; 1 generic (fp32 math) kernel; 2 MFMA flash kernel (tile by tile);
+                               3 whole-sequence ViT kernel (bidirectional, unmasked, d = 64, 65 / 257 tokens) */
 } vcla_attn_args;
 
 /* o = softmax(scale * q k^T + mask) v */

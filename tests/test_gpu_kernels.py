@@ -684,6 +684,44 @@ def test_attention_mfma(lib, B, H, Tq, Tk, D, causal):
     _cmp(f"attn_mfma_vs_generic[Tq{Tq}Tk{Tk}D{D}]", got, gen.float(), atol=1.6e-2)
 
 
+@pytest.mark.parametrize("B,H,T", [(64, 16, 257), (3, 2, 257), (1, 1, 257), (2, 4, 65), (40, 4, 65)])
+def test_attention_vit_whole_sequence(lib, B, H, T):
+    """force_kernel 3: the whole-sequence ViT self-attention (4 waves x 64 query rows on MFMA, the 257th key and the 257th query row on
+    the VALU, the last row merged from per-wave partials) against the fp32 reference, through the strided fused-qkv layout the engine
+    uses; and the automatic dispatch (B * H >= 128) must give the same bits as the forced kernel."""
+    D = 64
+    g = torch.Generator().manual_seed(B * 7 + H + T)
+    qkv = bf16r(torch.randn(B, T, 3, H, D, generator=g) * 1.5)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))          # [B, H, T, D]
+    ref = _attn_ref(q, k, v, 1 / math.sqrt(D), False, None)
+    qkv_d = qkv.to(DEV, torch.bfloat16).contiguous()
+    L = lib.load()
+    outs = []
+    for fk in (3, 0, 2):
+        out = torch.full((B, T, H * D), 7.0, dtype=torch.bfloat16, device=DEV)
+        a = lib.AttnArgs()
+        e = 2
+        base = qkv_d.data_ptr()
+        a.q, a.k, a.v, a.o = base, base + H * D * e, base + 2 * H * D * e, out.data_ptr()
+        a.q_bs = a.k_bs = a.v_bs = T * 3 * H * D
+        a.q_hs = a.k_hs = a.v_hs = D
+        a.q_rs = a.k_rs = a.v_rs = 3 * H * D
+        a.o_bs, a.o_hs, a.o_rs = T * H * D, D, H * D
+        a.B, a.H, a.Tq, a.Tk, a.D = B, H, T, T, D
+        a.scale, a.causal, a.force_kernel = 1 / math.sqrt(D), 0, fk
+        lib.check(L.vcla_attention(C.byref(a), lib.dtype_code(torch.bfloat16), lib.stream_ptr()))
+        torch.cuda.synchronize()
+        _cmp(f"attention_vit[B{B}H{H}T{T},fk{fk}]", out, ref, atol=2e-2)
+        outs.append(out)
+    if B * H >= 128:
+        assert torch.equal(outs[0], outs[1])          # the dispatch picked the whole-sequence kernel
+    # shapes the kernel does not serve are refused, not mis-computed
+    a.Tq = a.Tk = 130
+    a.force_kernel = 3
+    with pytest.raises((ValueError, lib.VclaError)):
+        lib.check(L.vcla_attention(C.byref(a), lib.dtype_code(torch.bfloat16), lib.stream_ptr()))
+
+
 def test_attention_mfma_mask_and_strides(lib):
     # fused-qkv strides + left padding, as LLaMA prefill with a padded batch would issue it
     B, H, T, D = 2, 4, 70, 128

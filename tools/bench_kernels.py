@@ -436,7 +436,10 @@ def main():
             del kcs, vcs
     if "vitattn" in which:
         print("== MFMA flash attention, vision shapes; env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VCLA_")))
-        bench_attn("vit 224px (B=64)", 64, 16, 257, 257, 64, False, 2)
+        bench_attn("vit 224px (B=64) tile-by-tile", 64, 16, 257, 257, 64, False, 2)
+        bench_attn("vit 224px (B=64) whole-seq", 64, 16, 257, 257, 64, False, 3)
+        bench_attn("vit 224px (B=16) whole-seq", 16, 16, 257, 257, 64, False, 3)
+        bench_attn("vit 224px (B=256) whole-seq", 256, 16, 257, 257, 64, False, 3)
         bench_attn("vit 336px (B=32)", 32, 16, 577, 577, 64, False, 2)
         bench_attn("resampler (B=64)", 64, 16, 64, 321, 64, False, 2)
         bench_attn("llama prefill (B=64,T=128)", 64, 32, 128, 128, 128, True, 2)

@@ -9,6 +9,7 @@
 #define ATT_ROWS_PER_BLOCK 16
 
 int vcla_attention_mfma(const vcla_attn_args* a, void* stream);  // attention_mfma.hip
+int vcla_attention_vit(const vcla_attn_args* a, void* stream);   // attention_mfma.hip: whole-sequence ViT self-attention (force_kernel 3)
 bool vcla_attention_mfma_supported(const vcla_attn_args* a);
 
 // dot of q (fp32 in LDS) with one key row in global memory
@@ -166,6 +167,10 @@ extern "C" int vcla_attention(const vcla_attn_args* a, int dtype, void* stream) 
                      a->o_bs % 2 == 0, VCLA_ERR_BAD_SHAPE, "attention: V/O strides must be even");
     if (a->B == 0 || a->Tq == 0) return VCLA_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (a->force_kernel == 3) {
+        VCLA_REQUIRE(dtype == VCLA_BF16, VCLA_ERR_BAD_ARG, "attention: the whole-sequence ViT kernel needs bf16 activations");
+        return vcla_attention_vit(a, stream);
+    }
     if (a->force_kernel == 2 || (a->force_kernel == 0 && dtype == VCLA_BF16 && vcla_attention_mfma_supported(a))) {
         VCLA_REQUIRE(dtype == VCLA_BF16 && vcla_attention_mfma_supported(a), VCLA_ERR_BAD_ARG,
                      "attention: MFMA kernel does not support this problem");

@@ -25,6 +25,8 @@
 
 #define FA_KV 64
 
+bool vcla_attention_mfma_supported(const vcla_attn_args* a);
+
 template <int D> __device__ __forceinline__ int fa_k_off(int key, int ch) {
     if (D == 128) return key * 256 + ((ch ^ (key & 15)) << 4);
     return key * 128 + ((ch ^ ((key >> 1) & 7)) << 4);
@@ -333,6 +335,556 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_kernel(vcla_attn_args a) {
     }
 }
 
+// =================================================================== ViT self-attention, whole sequence per workgroup (round 4)
+// Bidirectional, unmasked, d = 64, Tq = Tk = NWM * 64 + 1 (ViT-L/14 at 224 px: 257 = 4 * 64 + 1 tokens).  The tile-by-tile kernel
+// above spent its time waiting: one key tile is ~0.9 us of MFMA + softmax work per workgroup against ~2 us of global latency per
+// tile and two workgroup barriers, and the 9th wave carried ONE valid query row (57 us per layer at B = 64, 12 % of the MFMA peak).
+// Here a workgroup is NWM waves, one (batch, head):
+//   * every K / V chunk of the sequence is requested up front and parked in LDS (64 + 64 KiB... no: 257 x 128 B x 2 = 64.25 KiB),
+//     ONE barrier, no workgroup synchronisation inside the key loop;
+//   * each wave owns 64 query rows = FOUR 16-row MFMA tiles: a K / V^T fragment read from LDS feeds 4 MFMAs instead of 2 (the LDS
+//     fragment traffic per flop halves), 64 MFMAs per key tile and wave;
+//   * the 257th KEY is folded in on the VALU after the tile loop (as above); the 257th QUERY ROW is computed on the VALU too, split
+//     over the waves: wave w scores it against the 64 keys of tile w (one key per lane, q . k on v_dot2 from LDS), forms its own
+//     (max, sum, sum p v[d = lane]) and parks them in LDS; wave 0 merges the NWM partials at the end.  No wave is spent on one row.
+// 4 waves x ~200 registers: two workgroups per CU (LDS 2 x 66 KiB), 8 waves -- the second workgroup's MFMAs run under the first
+// one's softmax.
+// ABL != 0: timing ablations for tools/bench_kernels.py (VCLA_ATTN_VIT_ABL; results are garbage): 1 = no last-row VALU phase, 2 = no v_exp
+// in the softmax, 3 = no key-tile loop at all (staging + epilogue only), 4 = tile loop without the softmax VALU work.
+template <int NWM, int ABL = 0>
+__global__ __launch_bounds__(NWM * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_kernel(vcla_attn_args a) {
+    constexpr int D = 64, KST = 2, DT = 4, CH = 8, QT = 4, NT = NWM * 64, NK = NWM * 64 + 1;
+    constexpr int KV_BYTES = NK * D * 2;                              // one operand image: [NK keys][128 B], chunk-swizzled
+    constexpr int NLD = (NK * CH + NT - 1) / NT;                      // staging loads per thread per operand
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];    // [K image][V image][NWM x 66 floats: last-row partials]
+    unsigned char* ks_all = lds_all;
+    unsigned char* vs_all = lds_all + KV_BYTES;
+    float* part = reinterpret_cast<float*>(lds_all + 2 * KV_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const bf16_t* qb = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* kb = (const bf16_t*)a.k + b * a.k_bs + h * a.k_hs;
+    const bf16_t* vb = (const bf16_t*)a.v + b * a.v_bs + h * a.v_hs;
+    bf16_t* ob = (bf16_t*)a.o + b * a.o_bs + h * a.o_hs;
+    const int ql = lane & 15, g = lane >> 4;
+    const int qw = wave * 64;
+    const float sl2 = a.scale * 1.44269504088896340736f;
+
+    // ---- request everything: the wave's Q fragments, the last query row (every lane the whole row: broadcast loads), all of K and V
+    bf16x8_t qf[QT][KST];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            qf[qt][s] = *reinterpret_cast<const bf16x8_t*>(qb + (int64_t)(qw + qt * 16 + ql) * a.q_rs + s * 32 + g * 8);
+    bf16x8_t qx[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) qx[c] = *reinterpret_cast<const bf16x8_t*>(qb + (int64_t)(NK - 1) * a.q_rs + c * 8);
+    {
+        u32x4_t rk[NLD], rv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int id0 = i * NT + tid, id = id0 < NK * CH ? id0 : NK * CH - 1;
+            const int key = id / CH, ch = id % CH;
+            rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)key * a.k_rs + ch * 8);
+            rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)key * a.v_rs + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int id = i * NT + tid, key = id / CH, ch = id % CH;
+            if (id < NK * CH) {
+                *reinterpret_cast<u32x4_t*>(ks_all + fa_k_off<D>(key, ch)) = rk[i];
+                *reinterpret_cast<u32x4_t*>(vs_all + fa_v_off<D>(key, ch * 8)) = rv[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- last query row against this wave's 64 keys (wave 0: + the last key), on the VALU
+    if constexpr (ABL != 1) {
+        auto qdot = [&](int key) {
+            float d_ = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const bf16x8_t kc = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(key, c));
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 0, 1), __builtin_shufflevector(kc, kc, 0, 1), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 2, 3), __builtin_shufflevector(kc, kc, 2, 3), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 4, 5), __builtin_shufflevector(kc, kc, 4, 5), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 6, 7), __builtin_shufflevector(kc, kc, 6, 7), d_, false);
+            }
+            return d_ * sl2;
+        };
+        const float sc = qdot(qw + lane);
+        const float sx = qdot(NK - 1);                              // wave-uniform (broadcast LDS reads); counted by wave 0 only
+        float mw = wave_max(sc);
+        if (wave == 0) mw = fmaxf(mw, sx);
+        const float p = __builtin_amdgcn_exp2f(sc - mw);
+        const float px = wave == 0 ? __builtin_amdgcn_exp2f(sx - mw) : 0.f;
+        const float lw = wave_sum(p) + px;
+        // o_w[d = lane] = sum over the wave's keys of p_key * V[key][lane]
+        float acc = px * bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(NK - 1, lane)));
+#pragma unroll 16
+        for (int kk = 0; kk < 64; ++kk) {
+            const float pk = __shfl(p, kk, 64);
+            acc = __builtin_fmaf(pk, bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(qw + kk, lane))), acc);
+        }
+        part[wave * 66 + lane] = acc;
+        if (lane == 0) { part[wave * 66 + 64] = mw; part[wave * 66 + 65] = lw; }
+    }
+
+    // ---- the wave's 64 query rows against all key tiles
+    f32x4_t o[QT][DT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    for (int tile = 0; tile < (ABL == 3 ? 0 : NWM); ++tile) {
+        const unsigned char* ks = ks_all + tile * (64 * D * 2);
+        const auto vbase = (__attribute__((address_space(3))) unsigned char*)lds_all + KV_BYTES + tile * (64 * D * 2);
+        f32x4_t sacc[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s * 4 + g));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[qt][t], 0, 0, 0);
+            }
+        bf16x8_t pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
+            mx *= sl2;
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);                 // finite: nothing is masked here
+            const float alpha = exp2f(m_run[qt] - m_new);             // exp2(-inf) = 0 on the first tile
+            m_run[qt] = m_new;
+            float ps = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p;
+                    if constexpr (ABL == 2) p = __builtin_fmaf(sacc[qt][t][r], sl2, -m_new);
+                    else if constexpr (ABL == 4) p = sacc[qt][t][r];
+                    else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][t][r], sl2, -m_new));
+                    pv[t * 4 + r] = p;
+                    if constexpr (ABL != 4) ps += p;
+                }
+            l_run[qt] = l_run[qt] * alpha + ps;
+            if constexpr (ABL != 4) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 u;
+                u.x = pack_bf2(pv[(2 * s) * 4 + 0], pv[(2 * s) * 4 + 1]);
+                u.y = pack_bf2(pv[(2 * s) * 4 + 2], pv[(2 * s) * 4 + 3]);
+                u.z = pack_bf2(pv[(2 * s + 1) * 4 + 0], pv[(2 * s + 1) * 4 + 1]);
+                u.w = pack_bf2(pv[(2 * s + 1) * 4 + 2], pv[(2 * s + 1) * 4 + 3]);
+                pf[qt][s] = __builtin_bit_cast(bf16x8_t, u);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kr = g * 4 + (ql >> 2), dc = dt * 16 + (ql & 3) * 4;
+                const fa_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s) * 16 + kr, dc)));
+                const fa_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s + 1) * 16 + kr, dc)));
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s], o[qt][dt], 0, 0, 0);
+            }
+    }
+    // ---- the last key (NK - 1) on the VALU, from LDS: lane (ql, g) holds Q[q][s*32 + g*8 .. +8] and O[q][dt*16 + g*4 .. +4]
+    {
+        bf16x8_t kx[KST];
+#pragma unroll
+        for (int s = 0; s < KST; ++s) kx[s] = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(NK - 1, s * 4 + g));
+        uint2 vx[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vx[dt] = *reinterpret_cast<const uint2*>(vs_all + fa_v_off<D>(NK - 1, dt * 16 + g * 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float d_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < KST; ++s) {
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 0, 1), __builtin_shufflevector(kx[s], kx[s], 0, 1), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 2, 3), __builtin_shufflevector(kx[s], kx[s], 2, 3), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 4, 5), __builtin_shufflevector(kx[s], kx[s], 4, 5), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 6, 7), __builtin_shufflevector(kx[s], kx[s], 6, 7), d_, false);
+            }
+            d_ += __shfl_xor(d_, 16, 64);
+            d_ += __shfl_xor(d_, 32, 64);
+            const float sx = d_ * sl2;
+            const float m_new = fmaxf(m_run[qt], sx);
+            const float alpha = exp2f(m_run[qt] - m_new), px = __builtin_amdgcn_exp2f(sx - m_new);
+            m_run[qt] = m_new;
+            l_run[qt] = l_run[qt] * alpha + (g == 0 ? px : 0.f);   // l is a per-lane partial, summed over g below
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[qt][dt][0] = __builtin_fmaf(px, __uint_as_float(vx[dt].x << 16), o[qt][dt][0] * alpha);
+                o[qt][dt][1] = __builtin_fmaf(px, __uint_as_float(vx[dt].x & 0xffff0000u), o[qt][dt][1] * alpha);
+                o[qt][dt][2] = __builtin_fmaf(px, __uint_as_float(vx[dt].y << 16), o[qt][dt][2] * alpha);
+                o[qt][dt][3] = __builtin_fmaf(px, __uint_as_float(vx[dt].y & 0xffff0000u), o[qt][dt][3] * alpha);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        bf16_t* orow = ob + (int64_t)(qw + qt * 16 + ql) * a.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float v[4] = {o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv};
+            Act<bf16_t>::st4(orow + dt * 16 + g * 4, v);
+        }
+    }
+    // ---- merge the NWM partials of the last query row
+    __syncthreads();
+    if (wave == 0) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) m = fmaxf(m, part[w * 66 + 64]);
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) {
+            const float f = exp2f(part[w * 66 + 64] - m);
+            l = __builtin_fmaf(part[w * 66 + 65], f, l);
+            acc = __builtin_fmaf(part[w * 66 + lane], f, acc);
+        }
+        ob[(int64_t)(NK - 1) * a.o_rs + lane] = f2bf(acc / l);
+    }
+}
+
+// ---- the same kernel with direct-to-LDS staging, pipelined against the key tiles (NWM = 4 only).
+// The register-staged form above is lock-stepped: both co-resident workgroups of a CU request their 96 KiB at launch, wait ~25 us for them
+// (135 MB per launch through L2: the staging + epilogue alone measure 33 of the 48 us, VCLA_ATTN_VIT_ABL=3), then compute.  Here every byte
+// moves with global_load_lds_dwordx4 issued from inline asm (no staging registers, hipcc neither counts nor drains them) in the order
+// the tile loop consumes them, and vmcnt is counted by hand: tile t is computed once the wave's own pieces of tile t have landed and the
+// workgroup has met at a bare s_barrier, while the later tiles are still in flight.  LDS images are lane-linear per DMA instruction, so the
+// bank swizzles of fa_k_off / fa_v_off are applied on the SOURCE side (the lane of slot p fetches the chunk that belongs there).
+// Q takes the same road: each wave DMAs its own 64 query rows (8 KiB) into the LDS area of key tiles 2 / 3, reads its MFMA fragments out
+// of it (swizzled like K: conflict-free ds_read_b128), and only then are tiles 2 and 3 requested -- no register-destination load, whose
+// completion the compiler could not see, anywhere.  The last key / value / query rows ride in three padded 1 KiB pieces.
+__device__ __forceinline__ void fa_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void fa_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void fa_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_dma_kernel(vcla_attn_args a) {
+    constexpr int NWM = 4, D = 64, KST = 2, DT = 4, QT = 4, NK = NWM * 64 + 1;
+    constexpr int ROWS = NWM * 64 + 8;                                 // image rows incl. the padded piece of the last key
+    constexpr int IMG = ROWS * 128;                                    // one operand image
+    constexpr int TILE = 64 * 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];    // [K image][V image][last query row piece 1 KiB][NWM x 66 floats]
+    unsigned char* ks_all = lds_all;
+    unsigned char* vs_all = lds_all + IMG;
+    unsigned char* qx_row = lds_all + 2 * IMG;
+    float* part = reinterpret_cast<float*>(lds_all + 2 * IMG + 1024);
+    typedef __attribute__((address_space(3))) void* lds_p;
+    const unsigned lds_u = (unsigned)(uintptr_t)(lds_p)lds_all;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const bf16_t* qb = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* kb = (const bf16_t*)a.k + b * a.k_bs + h * a.k_hs;
+    const bf16_t* vb = (const bf16_t*)a.v + b * a.v_bs + h * a.v_hs;
+    bf16_t* ob = (bf16_t*)a.o + b * a.o_bs + h * a.o_hs;
+    const int ql = lane & 15, g = lane >> 4;
+    const int qw = wave * 64;
+    const float sl2 = a.scale * 1.44269504088896340736f;
+
+    // ---- DMA lane maps: lane = (row within the 8-row piece, 16-byte slot p); the chunk that belongs in slot p of `row`
+    const int prow = lane >> 3, pslot = lane & 7;
+    auto k_chunk = [&](int row) { return pslot ^ ((row >> 1) & 7); };                                   // inverse of fa_k_off (an involution)
+    auto v_chunk = [&](int row) { return ((((pslot >> 1) ^ (row >> 1)) & 3) << 1) + (pslot & 1); };    // inverse of fa_v_off's 32-byte block swizzle
+    // the wave's Q rows -> its 8 KiB staging area inside the images of key tiles 2 / 3 (waves 0, 1: K image; waves 2, 3: V image)
+    const unsigned qarea = lds_u + (wave < 2 ? 0 : IMG) + 2 * TILE + (wave & 1) * TILE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = j * 8 + prow;
+        fa_dma16(qb + (int64_t)(qw + row) * a.q_rs + k_chunk(row) * 8, __builtin_amdgcn_readfirstlane(qarea + j * 1024));
+    }
+    // key tiles: 16 pieces per tile (8 K + 8 V), 4 per wave
+    auto issue_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;                  // 8 rows
+            const int row = t * 64 + piece * 8 + prow;
+            fa_dma16(kb + (int64_t)row * a.k_rs + k_chunk(row) * 8, __builtin_amdgcn_readfirstlane(lds_u + (t * 64 + piece * 8) * 128));
+            fa_dma16(vb + (int64_t)row * a.v_rs + v_chunk(row) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (t * 64 + piece * 8) * 128));
+        }
+    };
+    issue_tile(0);
+    issue_tile(1);
+    {   // the last key's K / V rows and the last query row: three padded 8-row pieces (rows clamped to the last one), one per wave (wave 3 repeats wave 2's)
+        const int row = NK - 1;
+        if (wave == 0) fa_dma16(kb + (int64_t)row * a.k_rs + k_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + (NK - 1) * 128));
+        else if (wave == 1) fa_dma16(vb + (int64_t)row * a.v_rs + v_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (NK - 1) * 128));
+        else fa_dma16(qb + (int64_t)row * a.q_rs + pslot * 8, __builtin_amdgcn_readfirstlane(lds_u + 2 * IMG));
+    }
+    // ---- Q fragments out of the staging area (B port): lane (q = ql, g) holds Q[q][ks*32 + g*8 .. +8]
+    fa_vmcnt<9>();                                                     // the wave's own 8 Q pieces have landed (tiles 0, 1 and the last rows may not have)
+    bf16x8_t qf[QT][KST];
+    {
+        const unsigned char* qa = lds_all + (wave < 2 ? 0 : IMG) + 2 * TILE + (wave & 1) * TILE;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int s = 0; s < KST; ++s) qf[qt][s] = *reinterpret_cast<const bf16x8_t*>(qa + fa_k_off<D>(qt * 16 + ql, s * 4 + g));
+    }
+    fa_lds_barrier();                                                  // every wave has its Q in registers: the staging areas may be overwritten
+    issue_tile(2);
+    issue_tile(3);
+
+    f32x4_t o[QT][DT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    auto tile_body = [&](int tile) {
+        const unsigned char* ks = ks_all + tile * TILE;
+        const auto vbase = (__attribute__((address_space(3))) unsigned char*)lds_all + IMG + tile * TILE;
+        f32x4_t sacc[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s * 4 + g));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[qt][t], 0, 0, 0);
+            }
+        bf16x8_t pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
+            mx *= sl2;
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float ps = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][t][r], sl2, -m_new));
+                    pv[t * 4 + r] = p;
+                    ps += p;
+                }
+            l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 u;
+                u.x = pack_bf2(pv[(2 * s) * 4 + 0], pv[(2 * s) * 4 + 1]);
+                u.y = pack_bf2(pv[(2 * s) * 4 + 2], pv[(2 * s) * 4 + 3]);
+                u.z = pack_bf2(pv[(2 * s + 1) * 4 + 0], pv[(2 * s + 1) * 4 + 1]);
+                u.w = pack_bf2(pv[(2 * s + 1) * 4 + 2], pv[(2 * s + 1) * 4 + 3]);
+                pf[qt][s] = __builtin_bit_cast(bf16x8_t, u);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kr = g * 4 + (ql >> 2), dc = dt * 16 + (ql & 3) * 4;
+                const fa_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s) * 16 + kr, dc)));
+                const fa_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s + 1) * 16 + kr, dc)));
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s], o[qt][dt], 0, 0, 0);
+            }
+    };
+    // DMA queue of a wave now: [tile 0: 4][tile 1: 4][last rows: 1][tile 2: 4][tile 3: 4]; tile t is ready once nothing older than the
+    // pieces behind it is outstanding (vmcnt retires in order) and every wave has said so
+#pragma unroll 1
+    for (int tile = 0; tile < NWM; ++tile) {
+        if (tile == 0) fa_vmcnt<13>();
+        else if (tile == 1) fa_vmcnt<9>();
+        else if (tile == 2) fa_vmcnt<4>();
+        else fa_vmcnt<0>();
+        fa_lds_barrier();
+        tile_body(tile);
+    }
+
+    // ---- the last key (NK - 1) on the VALU, from LDS
+    {
+        bf16x8_t kx[KST];
+#pragma unroll
+        for (int s = 0; s < KST; ++s) kx[s] = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(NK - 1, s * 4 + g));
+        uint2 vx[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vx[dt] = *reinterpret_cast<const uint2*>(vs_all + fa_v_off<D>(NK - 1, dt * 16 + g * 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float d_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < KST; ++s) {
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 0, 1), __builtin_shufflevector(kx[s], kx[s], 0, 1), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 2, 3), __builtin_shufflevector(kx[s], kx[s], 2, 3), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 4, 5), __builtin_shufflevector(kx[s], kx[s], 4, 5), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 6, 7), __builtin_shufflevector(kx[s], kx[s], 6, 7), d_, false);
+            }
+            d_ += __shfl_xor(d_, 16, 64);
+            d_ += __shfl_xor(d_, 32, 64);
+            const float sx = d_ * sl2;
+            const float m_new = fmaxf(m_run[qt], sx);
+            const float alpha = exp2f(m_run[qt] - m_new), px = __builtin_amdgcn_exp2f(sx - m_new);
+            m_run[qt] = m_new;
+            l_run[qt] = l_run[qt] * alpha + (g == 0 ? px : 0.f);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[qt][dt][0] = __builtin_fmaf(px, __uint_as_float(vx[dt].x << 16), o[qt][dt][0] * alpha);
+                o[qt][dt][1] = __builtin_fmaf(px, __uint_as_float(vx[dt].x & 0xffff0000u), o[qt][dt][1] * alpha);
+                o[qt][dt][2] = __builtin_fmaf(px, __uint_as_float(vx[dt].y << 16), o[qt][dt][2] * alpha);
+                o[qt][dt][3] = __builtin_fmaf(px, __uint_as_float(vx[dt].y & 0xffff0000u), o[qt][dt][3] * alpha);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        bf16_t* orow = ob + (int64_t)(qw + qt * 16 + ql) * a.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float v[4] = {o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv};
+            Act<bf16_t>::st4(orow + dt * 16 + g * 4, v);
+        }
+    }
+    // ---- last query row against this wave's 64 keys (wave 0: + the last key), on the VALU; partials merged by wave 0
+    {
+        bf16x8_t qx[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qx[c] = *reinterpret_cast<const bf16x8_t*>(qx_row + c * 16);      // broadcast reads
+        auto qdot = [&](int key) {
+            float d_ = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8_t kc = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(key, c));
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 0, 1), __builtin_shufflevector(kc, kc, 0, 1), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 2, 3), __builtin_shufflevector(kc, kc, 2, 3), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 4, 5), __builtin_shufflevector(kc, kc, 4, 5), d_, false);
+                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 6, 7), __builtin_shufflevector(kc, kc, 6, 7), d_, false);
+            }
+            return d_ * sl2;
+        };
+        const float sc = qdot(qw + lane);
+        const float sx = qdot(NK - 1);
+        float mw = wave_max(sc);
+        if (wave == 0) mw = fmaxf(mw, sx);
+        const float p = __builtin_amdgcn_exp2f(sc - mw);
+        const float px = wave == 0 ? __builtin_amdgcn_exp2f(sx - mw) : 0.f;
+        const float lw = wave_sum(p) + px;
+        float acc = px * bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(NK - 1, lane)));
+#pragma unroll 8
+        for (int kk = 0; kk < 64; ++kk) {
+            const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), kk));    // SGPR broadcast, no LDS round trip
+            acc = __builtin_fmaf(pk, bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(qw + kk, lane))), acc);
+        }
+        part[wave * 66 + lane] = acc;
+        if (lane == 0) { part[wave * 66 + 64] = mw; part[wave * 66 + 65] = lw; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) m = fmaxf(m, part[w * 66 + 64]);
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) {
+            const float f = exp2f(part[w * 66 + 64] - m);
+            l = __builtin_fmaf(part[w * 66 + 65], f, l);
+            acc = __builtin_fmaf(part[w * 66 + lane], f, acc);
+        }
+        ob[(int64_t)(NK - 1) * a.o_rs + lane] = f2bf(acc / l);
+    }
+}
+
+static bool attn_vit_shape(const vcla_attn_args* a) {
+    if (a->causal || a->key_mask || a->tk_dev || a->D != 64 || a->Tq != a->Tk) return false;
+    return a->Tq == 65 || a->Tq == 257;      // NWM = 1, 4 (a 2-wave instance spills its 72 staging registers; 129 tokens is no ViT geometry here)
+}
+
+int vcla_attention_vit(const vcla_attn_args* a, void* stream) {
+    VCLA_REQUIRE(attn_vit_shape(a) && vcla_attention_mfma_supported(a) && vcla_aligned(a->o, 2), VCLA_ERR_BAD_ARG,
+                 "attention: the whole-sequence ViT kernel needs an unmasked bidirectional d = 64 self-attention over 65 / 257 tokens");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(1, a->H, a->B);
+    static const int abl_env = getenv("VCLA_ATTN_VIT_ABL") ? atoi(getenv("VCLA_ATTN_VIT_ABL")) : 0;
+#define VIT_GO(NWM_)                                                                                                 \
+    {                                                                                                                \
+        auto kern = attn_vit_kernel<NWM_>;                                                                           \
+        if ((NWM_) == 4 && abl_env == 1) kern = attn_vit_kernel<4, 1>;                                              \
+        if ((NWM_) == 4 && abl_env == 2) kern = attn_vit_kernel<4, 2>;                                              \
+        if ((NWM_) == 4 && abl_env == 3) kern = attn_vit_kernel<4, 3>;                                              \
+        if ((NWM_) == 4 && abl_env == 4) kern = attn_vit_kernel<4, 4>;                                              \
+        const size_t lds = (size_t)2 * ((NWM_) * 64 + 1) * 128 + (size_t)(NWM_) * 66 * 4;                             \
+        static bool attr_set[VCLA_MAX_DEVICES] = {};                                                                 \
+        if (lds > 64 * 1024) { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; } \
+        kern<<<grid, (NWM_) * 64, lds, s>>>(*a);                                                                     \
+    }
+    static const int vit_form = getenv("VCLA_ATTN_VIT") ? atoi(getenv("VCLA_ATTN_VIT")) : 2;   // 1 = register-staged form, 2 = direct-to-LDS pipelined form (257 tokens)
+    if (a->Tq == 257 && vit_form != 1 && abl_env == 0) {
+        auto kern = attn_vit_dma_kernel;
+        const size_t lds = (size_t)2 * 264 * 128 + 1024 + 4 * 66 * 4;
+        static bool attr_set[VCLA_MAX_DEVICES] = {};
+        const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set);
+        if (rc_) return rc_;
+        kern<<<grid, 256, lds, s>>>(*a);
+    } else if (a->Tq == 257) VIT_GO(4)
+    else VIT_GO(1)
+#undef VIT_GO
+    VCLA_CHECK_LAUNCH("attn_vit_kernel");
+    return VCLA_OK;
+}
+
 bool vcla_attention_mfma_supported(const vcla_attn_args* a) {
     if (a->D != 64 && a->D != 128) return false;
     if (a->tk_dev) return false;           // decode (Tq = 1) stays on the generic kernel
@@ -349,6 +901,9 @@ bool vcla_attention_mfma_supported(const vcla_attn_args* a) {
 int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const int nw_env = getenv("VCLA_ATTN_MFMA_NW") ? atoi(getenv("VCLA_ATTN_MFMA_NW")) : 0;   // A/B runs: force 4
+    // ViT self-attention (65 / 129 / 257 tokens, d = 64) with at least half a round of workgroups: the whole-sequence kernel
+    static const int vit_env = getenv("VCLA_ATTN_VIT") ? atoi(getenv("VCLA_ATTN_VIT")) : 1;           // A/B runs: 0 = the tile-by-tile kernel
+    if (vit_env && a->force_kernel != 2 && attn_vit_shape(a) && (int64_t)a->B * a->H >= 128) return vcla_attention_vit(a, stream);
     // waves per workgroup: bidirectional sequences longer than one 128-row block go 288 rows at a time (ViT-L/14 224 px: the
     // whole sequence), 64-query cross attention (resampler) needs only 2 waves
     int nw = 4;
