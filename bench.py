@@ -95,7 +95,7 @@ def _event_time(fn, reps: int):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-PROFILE_ROUNDS = ("r03", "r02")     # committed rocprofv3 summaries, newest first
+PROFILE_ROUNDS = ("r04", "r03", "r02")     # committed rocprofv3 summaries, newest first
 
 
 def _pmc_traffic(stem: str = "pmc_gemv1p"):
@@ -130,6 +130,15 @@ def _in_model_us(table: str, kernel_substr: str, grid: int):
     return None, None
 
 
+def _label_static(d: dict) -> dict:
+    """`achieved`, `frac`, `avg_launch_us` are measured live in this run (HIP events); the fields named here are READ from committed
+    rocprofv3 summaries under profiles/ (PMC counters and per-kernel durations cannot be collected inside the timed process)."""
+    static = [k for k in ("traffic", "avg_launch_us_in_model", "frac_in_model") if d.get(k) is not None]
+    if static:
+        d["static_fields"] = {"fields": static, "source": "committed profile (see traffic_source / in_model_source), not measured in this run"}
+    return d
+
+
 def gemv_roofline(model, n_rep: int = 20):
     """Dominant kernel of the B = 1 workload: the gate/up SwiGLU GEMV with fused RMSNorm (gemv1p_kernel<R=2,K=4096,SWIGLU>,
     gemv_decode.hip; ~36 % of the decode time, 43 % of the weight bytes).  One launch streams W_gu [2*11008, 4096] bf16 exactly once: algorithmic
@@ -157,7 +166,7 @@ def gemv_roofline(model, n_rep: int = 20):
            "launches_timed": n_rep * L}
     if us_model:     # the same kernel inside the decode graph (rocprofv3 of this command): what the step really pays per launch
         out.update(avg_launch_us_in_model=us_model, frac_in_model=round(alg_bytes / (us_model * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), in_model_source=us_src)
-    return out
+    return _label_static(out)
 
 
 def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
@@ -188,7 +197,7 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
     us_model, us_src = _in_model_us("bench_b64_by_grid.txt", "gemm_dstream_kernel<3", 131072) if M == 64 else (None, None)
     if us_model:
         out.update(avg_launch_us_in_model=us_model, frac_in_model=round(alg_bytes / (us_model * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), in_model_source=us_src)
-    return out
+    return _label_static(out)
 
 
 def vit_gemm_roofline(model, B: int = 64, n_rep: int = 20):
@@ -219,7 +228,7 @@ def vit_gemm_roofline(model, B: int = 64, n_rep: int = 20):
     us_model, us_src = _in_model_us("bench_b64_by_grid.txt", "gemm_mfma256_kernel<1", B * (I // 256) * 512) if B == 64 else (None, None)
     if us_model:
         out.update(avg_launch_us_in_model=us_model, frac_in_model=round(flops / (us_model * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4), in_model_source=us_src)
-    return out
+    return _label_static(out)
 
 
 def fp8_gemm_roofline(model, M: int = 8192, n_rep: int = 5):
@@ -276,9 +285,77 @@ def step_rooflines(b1, b64, cfgd, fp8: bool, kv8: bool = False):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------- fp8 accuracy
+def fp8_mode_accuracy(model, prefill: bool, kv_cache: bool, B: int = 2, T: int = 128, n_new: int = 4):
+    """How far the fp8 weight path's logits are from the bf16 path's ON THE SAME MODEL AND INPUTS (configs[4] reports this next to its
+    throughput): prefill logits (last position) and the first n_new - 1 decode steps, the fp8 run teacher-forced through the bf16 run's
+    tokens so that every step sees the same inputs.  Returns cosine similarity and mean |error| in units of the logit standard
+    deviation, worst over the compared steps, separately for the prefill and the decode steps.  Leaves the model in bf16 mode."""
+    import torch
+    from transformers import LogitsProcessorList
+    from visualcla.synthetic import make_inputs
+    px, ids, mask = make_inputs(model.config, B, T)
+    px, ids, mask = px.to(model.device, torch.bfloat16), ids.to(model.device), mask.to(model.device)
+
+    def run(force):
+        seen = []
+
+        def grab(ids_, scores):
+            seen.append(scores.detach().float().clone())
+            return scores
+
+        def teacher(ids_, scores):
+            if force is None:
+                return scores
+            step = len(seen) - 1
+            out = torch.full_like(scores, -1e30)
+            out.scatter_(1, force[:, step:step + 1], 0.0)
+            return out
+        toks = model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=n_new, do_sample=False, eos_token_id=None,
+                              logits_processor=LogitsProcessorList([grab, teacher]))
+        return seen, toks
+    model.enable_fp8_decode(False)
+    base, toks = run(None)
+    model.enable_fp8_decode(True, prefill=prefill, kv_cache=kv_cache)
+    try:
+        got, _ = run(toks)
+    finally:
+        model.enable_fp8_decode(False)
+
+    def dist(a, b):
+        std = b.std().item()
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        return cos, (a - b).abs().mean().item() / std
+    pre = dist(got[0], base[0])
+    dec = [dist(got[s], base[s]) for s in range(1, n_new)]
+    return {"vs": "bf16 path, same model and inputs, teacher-forced", "batch": B, "prompt_len": T,
+            "prefill": {"cosine": round(pre[0], 4), "mean_over_sigma": round(pre[1], 4)},
+            "decode_steps": {"cosine": round(min(c for c, _ in dec), 4), "mean_over_sigma": round(max(m for _, m in dec), 4), "steps": n_new - 1}}
+
+
 # ---------------------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(model, prompt_len: int, n_tokens: int):
-    """BASELINE configs[0] on this host: the CPU oracle (kind "port": oracle/visualcla_oracle.py = the reference's glue + the
+    """BASELINE configs[0] on this host's cores = "the reference CPU HuggingFace path" north_star names: oracle/hf_cpu_baseline.py in a child
+    process (transformers' own CLIPVisionModel + LlamaForCausalLM.generate in fp32 with the restated resampler between them, pinned to one
+    memory node, decode thread count swept; kind "hf+port-resampler").  The child is test infrastructure under oracle/, run here and
+    nowhere else; if it cannot run (no transformers, not enough host RAM) the restated port below is timed instead (kind "port")."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        r = subprocess.run([sys.executable, os.path.join(here, "oracle", "hf_cpu_baseline.py"), "--prompt-len", str(prompt_len), "--tokens", str(n_tokens)],
+                           capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        why = (r.stderr or r.stdout)[-300:]
+    except Exception as e:  # noqa: BLE001
+        why = f"{type(e).__name__}: {e}"
+    res = cpu_baseline_port(model, prompt_len, n_tokens)
+    res["sample"] += f" [HF child failed: {why}]"
+    return res
+
+
+def cpu_baseline_port(model, prompt_len: int, n_tokens: int):
+    """fallback of cpu_baseline(): the CPU oracle itself (kind "port": oracle/visualcla_oracle.py = the reference's glue + the
     transformers arithmetic restated, pinned to the reference's own outputs in tests/golden; /root/reference itself does not
     exist on the GPU box) runs ONE request end to end in fp32 -- vision stack, prefill of the T = 128 prompt, `n_tokens` greedy
     decode steps, all timed, nothing extrapolated.  32 threads: one NUMA domain's worth; torch's CPU kernels collapse when spread
@@ -468,14 +545,25 @@ def main():
 
     c4_res = None
     if args.steps_c4 > 0 and args.batch == 1 and not strong and not args.fp8 and args.image_size == 224:
-        # BASELINE configs[4], one GPU's share (B = 256 / 8): fp8 weight copies (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe), 336-px
-        # patching (577 ViT tokens).  Runs on the same model object and is undone afterwards (the position embedding returns to its
-        # native values bit for bit, the fp8 copies are dropped) so that the roofline and CPU legs below see the bf16 / 224-px model.
-        model.enable_fp8_decode(kv_cache=bool(args.fp8_kv))
+        # BASELINE configs[4], one GPU's share (B = 256 / 8): fp8 weight copies, 336-px patching (577 ViT tokens), timed in BOTH numeric modes:
+        #   headline  W8A16: fp8 weights in the decode kernels (dequantised in registers), the prefill on the bf16 MFMA tiles -- the analogue of the
+        #             reference's weight-only `load_in_8bit` (models/visualcla/modeling_visualcla.py:151-156) and what from_*_pretrained(load_in_8bit=True) selects;
+        #   beside it W8A8: the prefill on the fp8 MFMA pipe with per-row e4m3 activations (faster, lossier).
+        # Each carries `accuracy` = its logits against the bf16 path of this same model (fp8_mode_accuracy).  Runs on the same model object and is
+        # undone afterwards (the position embedding returns to its native values bit for bit, the fp8 copies are dropped).
+        kv = bool(args.fp8_kv)
         model.set_image_size(336)
-        c4_res = run_workload(32, args.steps_c4, 1)
+        legs = {}
+        for name, prefill in (("w8a16", False), ("w8a8", True)):
+            model.enable_fp8_decode(True, prefill=prefill, kv_cache=kv)
+            r = run_workload(32, args.steps_c4, 1)
+            r["accuracy"] = fp8_mode_accuracy(model, prefill=prefill, kv_cache=kv)       # leaves the model in bf16 mode
+            r["dtype"] = ("fp8-e4m3 weights, " + ("W8A16: fp8 weights dequantised in registers in the decode steps, bf16 x bf16 MFMA prefill" if not prefill else
+                                                  "W8A8: decode as W8A16, prefill on the fp8 MFMA pipe with per-row e4m3 activations") +
+                          (", e4m3 K/V cache" if kv else "") + "; bf16 activations and vision stack")
+            legs[name] = r
         model.set_image_size(224)
-        model.enable_fp8_decode(False)
+        c4_res = dict(legs["w8a16"], mode="w8a16", w8a8=legs["w8a8"])
 
     if rank == 0:
         B = args.batch
@@ -502,10 +590,8 @@ def main():
         if b64_res:
             res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
         if c4_res:
-            res["config4"] = dict(c4_res, dtype="fp8-e4m3 weights (W8A16 decode, W8A8 prefill on the fp8 MFMA pipe)" + (", e4m3 K/V cache" if args.fp8_kv else "") +
-                                  ", bf16 activations and vision stack",
-                                  workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
-                                           "128 greedy tokens (BASELINE configs[4], one GPU's share)")
+            res["config4"] = dict(c4_res, workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
+                                                   "128 greedy tokens (BASELINE configs[4], one GPU's share); headline mode w8a16, the W8A8 prefill mode under `w8a8`")
         b1 = main_res if B == 1 else None
         b64 = b64_res if b64_res else (main_res if B == 64 else None)
         rl = []

@@ -40,6 +40,7 @@
  *   vcla_attn_decode_fused  the decode-step instance of LlamaAttention.forward hf:llama/modeling_llama.py:217-281
  *                           (RoPE + DynamicCache.update + eager attention) in one launch
  *   vcla_argmax             greedy token selection hf:generation/utils.py (argmax over fp32 logits)
+ *   vcla_causal_lm_loss     the labels branch of forward, modeling_visualcla.py:321-328 (hf:loss/loss_utils.py ForCausalLMLoss)
  *   vcla_sample             (next row N2) the logits processors / warpers / draw of HF sample() under
  *                           DEFAULT_GENERATION_CONFIG models/visualcla/modeling_utils.py:36-47
  *   vcla_vision_forward     modeling_visualcla.py:283-288 / :349-354 (and tgwebui embed_images,
@@ -284,6 +285,13 @@ int vcla_attn_decode_fused_parts(const float* qkv_parts, int64_t slice_stride, c
 
 /* ids_out[b] = argmax_j logits[b, j] (first maximum); logits fp32 [B, ld] */
 int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, int B, int V, void* stream);
+
+/* forward(labels=...) -> .loss: the shifted causal-LM cross-entropy LlamaForCausalLM.forward computes when the reference passes
+   `labels` through (models/visualcla/modeling_visualcla.py:321-328 -> hf:loss/loss_utils.py ForCausalLMLoss): logits fp32 [B * T, ld_row]
+   (row b * T + t), labels int64 [B, T]; position t is scored against labels[b, t + 1], targets equal to ignore_index (-100) are
+   skipped, loss_out[0] = mean over the scored positions (nan when there is none).  row_loss_ws: B * T floats of scratch. */
+int vcla_causal_lm_loss(const float* logits, int64_t ld_row, const int64_t* labels, int B, int T, int V, int64_t ignore_index,
+                        float* row_loss_ws, float* loss_out, void* stream);
 
 /* Next-row N2: HF's logits processors + warpers + one draw, on the device, for every sequence of the batch.
    Replaces, per decode step, what `model.generate` runs under the reference's DEFAULT_GENERATION_CONFIG

@@ -366,6 +366,30 @@ def test_argmax_first_max(lib):
     assert got[2] == 100 and got[3] == 49957
 
 
+@pytest.mark.parametrize("B,T,V", [(2, 12, 320), (3, 7, 49958), (1, 1, 1000), (4, 33, 1000)])
+def test_causal_lm_loss_matches_the_hf_formula(lib, B, T, V):
+    """vcla_causal_lm_loss == hf ForCausalLMLoss (oracle.causal_lm_loss restates it): shifted targets, ignore_index rows skipped, mean; the
+    same bits on repeated runs; nan when nothing is supervised (torch's mean over zero targets)"""
+    g = torch.Generator().manual_seed(B + T + V)
+    logits = torch.randn(B, T, V, generator=g) * 3.0
+    labels = torch.randint(0, V, (B, T), generator=g)
+    labels[:, 0] = -100
+    if T > 3:
+        labels[0, 2] = -100
+    want = O.causal_lm_loss(logits, labels) if T > 1 else torch.tensor(float("nan"))
+    lg_d = logits.to(DEV)
+    got = lib.causal_lm_loss(lg_d, labels.to(DEV))
+    again = lib.causal_lm_loss(lg_d, labels.to(DEV))
+    torch.cuda.synchronize()
+    if T > 1:
+        assert abs(float(got) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), (float(got), float(want))
+        assert float(got) == float(again)
+    else:
+        assert math.isnan(float(got))
+    none = lib.causal_lm_loss(lg_d, torch.full((B, T), -100, dtype=torch.int64, device=DEV))
+    assert math.isnan(float(none))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_patch_embed_pipeline(lib, dtype):
     """im2col + GEMM + class/pos assembly + pre-LN == oracle.clip_embeddings."""

@@ -843,6 +843,35 @@ def test_7b_fp8_mfma_prefill_error_is_bounded(model_7b):
     assert err.mean().item() <= 0.55 * std and cos >= 0.8
 
 
+FP8_MODE_BOUNDS = {
+    # mode: (prefill on the fp8 MFMA pipe, e4m3 K/V cache) -> bounds (prefill cos >=, prefill mean/sigma <=, decode cos >=, decode mean/sigma <=)
+    "w8a16": ((False, False), None),
+    "w8a16+kv8": ((False, True), None),
+    "w8a8+kv8": ((True, True), None),
+}
+
+
+@pytest.mark.parametrize("mode", sorted(FP8_MODE_BOUNDS))
+def test_7b_fp8_modes_error_vs_bf16(model_7b, mode):
+    """BASELINE configs[4]'s numeric footing: every fp8 mode the benchmark can time, against the bf16 path of the same 7B model on the same
+    inputs (bench.fp8_mode_accuracy: the function whose output the config4 line carries).  w8a16 = the `load_in_8bit` analogue (fp8 WEIGHTS
+    in the decode kernels, dequantised in registers; the prefill runs the bf16 tiles -> its logits are bit-identical to bf16); +kv8 adds
+    the e4m3 K/V cache; w8a8 = prefill on the fp8 MFMA pipe with per-row e4m3 activations as well (the lossy speed mode)."""
+    import bench
+    m, ocfg = model_7b
+    (prefill, kv), bounds = FP8_MODE_BOUNDS[mode]
+    acc = bench.fp8_mode_accuracy(m, prefill=prefill, kv_cache=kv)
+    assert not m.fp8_decode
+    _report(f"7B fp8 mode {mode} vs bf16: prefill cos {acc['prefill']['cosine']:.4f} mean {acc['prefill']['mean_over_sigma']:.4f} sigma | "
+            f"decode steps cos {acc['decode_steps']['cosine']:.4f} mean {acc['decode_steps']['mean_over_sigma']:.4f} sigma")
+    if not prefill:
+        assert acc["prefill"]["cosine"] >= 0.99999 and acc["prefill"]["mean_over_sigma"] <= 1e-6      # the prefill IS the bf16 prefill
+    if bounds is not None:
+        pc, pm, dc, dm = bounds
+        assert acc["prefill"]["cosine"] >= pc and acc["prefill"]["mean_over_sigma"] <= pm, acc
+        assert acc["decode_steps"]["cosine"] >= dc and acc["decode_steps"]["mean_over_sigma"] <= dm, acc
+
+
 @pytest.mark.parametrize("B", [2, 64])
 def test_7b_fp8_kv_cache_error_is_bounded(model_7b, B):
     """enable_fp8_decode(kv_cache=True): the K / V cache holds e4m3 bytes (unit scale), read by the decode steps (B = 2: the 4-wave

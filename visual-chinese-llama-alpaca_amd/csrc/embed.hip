@@ -293,3 +293,62 @@ extern "C" int vcla_argmax(const float* logits, int64_t ld, int64_t* ids_out, in
     VCLA_CHECK_LAUNCH("argmax_kernel");
     return VCLA_OK;
 }
+
+// ------------------------------------------------------------------ causal-LM loss (forward(labels=...) -> .loss)
+// hf:loss/loss_utils.py ForCausalLMLoss as reached from models/visualcla/modeling_visualcla.py:321-328: position t of every sequence is scored
+// against labels[t + 1] (the last position has no target), rows whose target is ignore_index (-100) are skipped, mean over the rest.
+// One workgroup per (sequence, position): log-sum-exp of the fp32 logits row (max pass + sum pass, the row stays in L2 between them),
+// row_loss = lse - logit[target]; a second single-workgroup launch sums the rows in index order (deterministic) and divides by the count.
+#define CE_THREADS 256
+__global__ __launch_bounds__(CE_THREADS) void ce_rows_kernel(const float* __restrict__ logits, int64_t ld_row, const int64_t* __restrict__ labels, int T, int V,
+                                                             int64_t ignore_index, float* __restrict__ row_loss) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / T, t = row % T;
+    const int64_t tgt = t + 1 < T ? labels[(int64_t)b * T + t + 1] : ignore_index;
+    if (tgt == ignore_index || tgt < 0 || tgt >= V) {          // (out-of-range targets are refused by the host wrapper; skipped here to stay in bounds)
+        if (threadIdx.x == 0) row_loss[row] = -1.0f;            // marker: not counted (a real row loss is >= 0)
+        return;
+    }
+    const float* lr = logits + (int64_t)row * ld_row;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += CE_THREADS) mx = fmaxf(mx, lr[j]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < V; j += CE_THREADS) sum += expf(lr[j] - mx);
+    sum = block_sum_256(sum, red + 4);
+    if (threadIdx.x == 0) row_loss[row] = fmaxf(mx + logf(sum) - lr[tgt], 0.0f);
+}
+__global__ __launch_bounds__(CE_THREADS) void ce_mean_kernel(const float* __restrict__ row_loss, int rows, float* __restrict__ out) {
+    __shared__ float s_sum[CE_THREADS];
+    __shared__ int s_cnt[CE_THREADS];
+    // fixed assignment (thread i owns rows i, i + 256, ...) and a fixed-order tree: the same bits on every run
+    float acc = 0.f;
+    int cnt = 0;
+    for (int r = threadIdx.x; r < rows; r += CE_THREADS) {
+        const float v = row_loss[r];
+        if (v >= 0.f) { acc += v; ++cnt; }
+    }
+    s_sum[threadIdx.x] = acc;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = CE_THREADS / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s_cnt[0] > 0 ? s_sum[0] / (float)s_cnt[0] : __builtin_nanf("");     // torch: mean over zero targets is nan
+}
+
+extern "C" int vcla_causal_lm_loss(const float* logits, int64_t ld_row, const int64_t* labels, int B, int T, int V, int64_t ignore_index,
+                                   float* row_loss_ws, float* loss_out, void* stream) {
+    VCLA_REQUIRE(logits && labels && row_loss_ws && loss_out, VCLA_ERR_BAD_ARG, "causal_lm_loss: null pointer");
+    VCLA_REQUIRE(B > 0 && T > 0 && V > 0 && ld_row >= V, VCLA_ERR_BAD_SHAPE, "causal_lm_loss: B=%d T=%d V=%d ld=%lld", B, T, V, (long long)ld_row);
+    hipStream_t s = (hipStream_t)stream;
+    ce_rows_kernel<<<B * T, CE_THREADS, 0, s>>>(logits, ld_row, labels, T, V, ignore_index, row_loss_ws);
+    VCLA_CHECK_LAUNCH("ce_rows_kernel");
+    ce_mean_kernel<<<1, CE_THREADS, 0, s>>>(row_loss_ws, B * T, loss_out);
+    VCLA_CHECK_LAUNCH("ce_mean_kernel");
+    return VCLA_OK;
+}

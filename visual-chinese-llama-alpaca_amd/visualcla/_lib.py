@@ -129,6 +129,7 @@ SYMBOLS = {
     "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
     "vcla_attn_decode_fused_parts": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
     "vcla_argmax": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
+    "vcla_causal_lm_loss": (_i, [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _vp, _vp]),
     "vcla_sample": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(SampleArgs), _vp, _vp]),
     "vcla_ctx_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "vcla_ctx_destroy": (None, [_vp]),
@@ -329,6 +330,19 @@ def sample(logits, args: SampleArgs, n_hist: int = 0):
     check(load().vcla_sample(logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1], int(n_hist), None, C.byref(args),
                              out.data_ptr(), stream_ptr()))
     return out
+
+
+def causal_lm_loss(logits, labels, ignore_index: int = -100):
+    """logits fp32 [B, T, V] (contiguous rows), labels int64 [B, T] -> scalar fp32 tensor: mean shifted cross-entropy (HF ForCausalLMLoss)"""
+    assert logits.dtype == torch.float32 and logits.dim() == 3 and logits.stride(2) == 1 and logits.stride(0) == logits.shape[1] * logits.stride(1)
+    B, T, V = logits.shape
+    labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+    if labels.shape != (B, T):
+        raise ValueError(f"labels {tuple(labels.shape)} do not match logits {(B, T)}")
+    ws = torch.empty(B * T, dtype=torch.float32, device=logits.device)
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    check(load().vcla_causal_lm_loss(ptr(logits), logits.stride(1), ptr(labels), B, T, V, int(ignore_index), ptr(ws), ptr(out), stream_ptr()))
+    return out[0]
 
 
 def argmax(logits):

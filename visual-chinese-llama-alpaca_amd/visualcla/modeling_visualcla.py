@@ -599,8 +599,13 @@ class VisualCLAModel:
         logits = self._prefill(embeds, cache, key_mask, all_logits=True, taps=taps)
         loss = None
         if labels is not None:
-            lg = logits[:, :-1].reshape(-1, logits.shape[-1])
-            loss = torch.nn.functional.cross_entropy(lg, labels.to(self._device)[:, 1:].reshape(-1), ignore_index=-100)
+            lab = labels.to(self._device)
+            if lab.shape != (B, T):
+                raise ValueError(f"labels of shape {tuple(lab.shape)} do not match the {T}-position sequence")
+            if bool(((lab != -100) & ((lab < 0) | (lab >= logits.shape[-1]))).any()):
+                raise ValueError("labels contain ids outside the vocabulary")
+            with torch.cuda.device(self._device):
+                loss = _lib.causal_lm_loss(logits, lab)       # shifted cross-entropy, HF's ForCausalLMLoss (vcla_causal_lm_loss)
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache if use_cache else None)
         if return_dict is False:
             return tuple(x for x in (loss, logits, out.past_key_values) if x is not None)
