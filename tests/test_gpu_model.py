@@ -845,9 +845,12 @@ def test_7b_fp8_mfma_prefill_error_is_bounded(model_7b):
 
 FP8_MODE_BOUNDS = {
     # mode: (prefill on the fp8 MFMA pipe, e4m3 K/V cache) -> bounds (prefill cos >=, prefill mean/sigma <=, decode cos >=, decode mean/sigma <=)
-    "w8a16": ((False, False), None),
-    "w8a16+kv8": ((False, True), None),
-    "w8a8+kv8": ((True, True), None),
+    # measured on MI355X, random-init 7B (profiles/r04_parity_report.txt): w8a16 decode cos 0.963 / 0.218 sigma; +kv8 0.958 / 0.232;
+    # w8a8+kv8 prefill 0.894 / 0.368, decode 0.906 / 0.346.  (A random-init 32-layer network amplifies per-op noise ~10x: the bf16 path
+    # itself sits 0.04 sigma from fp32.)
+    "w8a16": ((False, False), (0.99999, 1e-6, 0.94, 0.27)),
+    "w8a16+kv8": ((False, True), (0.99999, 1e-6, 0.935, 0.28)),
+    "w8a8+kv8": ((True, True), (0.85, 0.45, 0.87, 0.42)),
 }
 
 
