@@ -175,7 +175,9 @@ def test_gemm_mfma128_splitk_single_image_shapes(lib, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi,fk", [(257 * 3, 768, 192, 0, 4), (257 * 5, 1000, 1024, 1, 4), (257 * 2, 3072, 1024, 3, 4), (257 * 9, 1024, 4096, 2, 5),
-                                          (257 * 64, 1024, 1024, 0, 0), (257 * 64, 4096, 1024, 1, 0), (257 * 32, 1024, 4096, 0, 0), (257 * 7, 2048, 512, 0, 0)])
+                                          (257 * 64, 1024, 1024, 0, 0), (257 * 64, 4096, 1024, 1, 0), (257 * 32, 1024, 4096, 0, 0), (257 * 7, 2048, 512, 0, 0),
+                                          # a LLaMA prefill whose B * T happens to be a multiple of 257 takes the same tiles: SwiGLU / in-place residual at those widths
+                                          (257 * 16, 22016, 4096, 3, 4), (257 * 16, 4096, 11008, 0, 4), (257 * 16, 22016, 4096, 3, 0)])
 def test_gemm_tile257(lib, M, N, K, epi, fk):
     """M = B * 257 (whole ViT sequences): the 256 x 256 kernel runs 257-row tiles -- the 257th row as a 17th MFMA strip whose other 15
     rows (the next tile's first rows) are computed and NOT stored -- instead of 256-row rounds + a tail launch.  Every row of every tile
