@@ -16,8 +16,9 @@ echo "== bench fp8"; timeout 600 python bench.py --fp8 --steps 3 --warmup 1 --no
 echo "== bench fp8 B=64"; timeout 900 python bench.py --fp8 --batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_fp8_b64.json; cut -c1-200 gpurun_out/${tag}_bench_fp8_b64.json
 echo "== bench fp8 336px B=32 (per-GPU share of configs[4])"; timeout 900 python bench.py --fp8 --image-size 336 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_336px_fp8_b32.json; cut -c1-200 gpurun_out/${tag}_bench_336px_fp8_b32.json
 echo "== bench sampled"; timeout 600 python bench.py --sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_sample.json; cut -c1-200 gpurun_out/${tag}_bench_sample.json
-echo "== bench strong scaling mode, 1 GPU (global batch 256 = 4 x 64 would not fit one step's buffers of the default; 64 here)"; timeout 900 python bench.py --global-batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_strong_gb64.json; cut -c1-200 gpurun_out/${tag}_bench_strong_gb64.json
-for cfg in "b1:--steps 2 --warmup 1 --steps-b64 0 --steps-c4 0 --no-cpu-baseline" "b64:--batch 64 --steps 1 --warmup 1 --steps-c4 0 --no-cpu-baseline"; do
+echo "== bench strong scaling mode on ONE GPU: global batch 256 (the N = 1 leg of north_star's '>= 6x images/sec 1 -> 8 GPUs at batch 256')"; timeout 900 python bench.py --gpus 1 --global-batch 256 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_strong_gb256.json; cut -c1-300 gpurun_out/${tag}_bench_strong_gb256.json
+echo "== bench B=128"; timeout 900 python bench.py --batch 128 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_b128.json; cut -c1-200 gpurun_out/${tag}_bench_b128.json
+for cfg in "b1:--steps 2 --warmup 1 --steps-b64 0 --steps-c4 0 --no-cpu-baseline" "b64:--batch 64 --steps 1 --warmup 1 --steps-c4 0 --no-cpu-baseline" "gb256:--global-batch 256 --steps 1 --warmup 1 --no-cpu-baseline"; do
   nm=${cfg%%:*}; args=${cfg#*:}
   echo "== rocprofv3 --kernel-trace --stats: bench.py $args"
   rm -rf gpurun_out/prof_$nm
@@ -40,5 +41,5 @@ for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_dstream.py gemm_dstream_kern
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_attn_decode.py attn_decode_flash_kernel ${tag}_pmc_attn_decode_b64_$(echo $c | tr A-Z a-z).txt; done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES; do pmc $c tools/pmc_gemm.py gemm_mfma256_kernel ${tag}_pmc_vit_fc1_mfma.txt VCLA_PMC_SHAPE=vit; done
 echo "== microbench"
-(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
+(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py dec256 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
 echo "== done"

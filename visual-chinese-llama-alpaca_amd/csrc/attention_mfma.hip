@@ -599,6 +599,14 @@ __device__ __forceinline__ void fa_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+#ifdef VCLA_G2_TIMELINE   // debug build only (make -C csrc timeline): per-workgroup phase stamps of the ViT attention, 100 MHz wall clock (tools/debug/vit_attn_timeline.py)
+__device__ unsigned long long* fa_timeline = nullptr;      // [workgroup][16]
+extern "C" int vcla_debug_set_vit_timeline(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fa_timeline), &p, sizeof(p)); }
+#define FA_STAMP(i_) do { if (fa_timeline && threadIdx.x == 0) fa_timeline[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 16 + (i_)] = wall_clock64(); } while (0)
+#else
+#define FA_STAMP(i_) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_dma_kernel(vcla_attn_args a) {
     constexpr int NWM = 4, D = 64, KST = 2, DT = 4, QT = 4, NK = NWM * 64 + 1;
     constexpr int ROWS = NWM * 64 + 8;                                 // image rows incl. the padded piece of the last key
@@ -621,6 +629,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ql = lane & 15, g = lane >> 4;
     const int qw = wave * 64;
     const float sl2 = a.scale * 1.44269504088896340736f;
+    FA_STAMP(0);
 
     // ---- DMA lane maps: lane = (row within the 8-row piece, 16-byte slot p); the chunk that belongs in slot p of `row`
     const int prow = lane >> 3, pslot = lane & 7;
@@ -653,6 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- Q fragments out of the staging area (B port): lane (q = ql, g) holds Q[q][ks*32 + g*8 .. +8]
     fa_vmcnt<9>();                                                     // the wave's own 8 Q pieces have landed (tiles 0, 1 and the last rows may not have)
+    FA_STAMP(1);
     bf16x8_t qf[QT][KST];
     {
         const unsigned char* qa = lds_all + (wave < 2 ? 0 : IMG) + 2 * TILE + (wave & 1) * TILE;
@@ -664,6 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fa_lds_barrier();                                                  // every wave has its Q in registers: the staging areas may be overwritten
     issue_tile(2);
     issue_tile(3);
+    FA_STAMP(2);
 
     f32x4_t o[QT][DT];
 #pragma unroll
@@ -748,7 +759,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else if (tile == 2) fa_vmcnt<4>();
         else fa_vmcnt<0>();
         fa_lds_barrier();
+        if (tile == 0) FA_STAMP(3);
         tile_body(tile);
+        FA_STAMP(4 + tile);
     }
 
     // ---- the last key (NK - 1) on the VALU, from LDS
@@ -785,19 +798,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+    // normalise O and pack it to bf16 now (32 registers across the last-row phase); it leaves through LDS as whole rows after the barrier below
+    uint2 opk[QT][DT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
-        bf16_t* orow = ob + (int64_t)(qw + qt * 16 + ql) * a.o_rs;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            float v[4] = {o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv};
-            Act<bf16_t>::st4(orow + dt * 16 + g * 4, v);
-        }
+        for (int dt = 0; dt < DT; ++dt)
+            opk[qt][dt] = make_uint2(pack_bf2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
     }
+    FA_STAMP(8);
     // ---- last query row against this wave's 64 keys (wave 0: + the last key), on the VALU; partials merged by wave 0
     {
         bf16x8_t qx[8];
@@ -831,7 +844,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         part[wave * 66 + lane] = acc;
         if (lane == 0) { part[wave * 66 + 64] = mw; part[wave * 66 + 65] = lw; }
     }
-    __syncthreads();
+    FA_STAMP(9);
+    __syncthreads();                      // every wave is done with K / V: the images are free
+    FA_STAMP(10);
+    // ---- O leaves as WHOLE ROWS: a lane of the MFMA layout owns 8 bytes of 16 different rows -- 16 dwordx2 stores per lane, each wave
+    // instruction touching 16 rows (the store tail of such an epilogue is issue-bound, MI355X_MICROARCH "attention epilogue store tail").
+    // Staged through the wave's own 8 KiB of the K image (chunk-swizzled: conflict-free 8-byte writes up to 2-way), then 8 dwordx4 stores
+    // per lane, every wave instruction = 8 full 128-byte rows.
+    {
+        unsigned char* os = ks_all + wave * TILE;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = qt * 16 + ql, c = dt * 2 + (g >> 1);
+                *reinterpret_cast<uint2*>(os + row * 128 + ((c ^ (row & 7)) << 4) + (g & 1) * 8) = opk[qt][dt];
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + prow;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(os + row * 128 + ((pslot ^ (row & 7)) << 4));
+            *reinterpret_cast<u32x4_t*>(ob + (int64_t)(qw + row) * a.o_rs + pslot * 8) = v;
+        }
+    }
     if (wave == 0) {
         float m = -INFINITY;
 #pragma unroll
@@ -845,6 +880,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         ob[(int64_t)(NK - 1) * a.o_rs + lane] = f2bf(acc / l);
     }
+    FA_STAMP(11);
 }
 
 static bool attn_vit_shape(const vcla_attn_args* a) {
@@ -871,7 +907,8 @@ int vcla_attention_vit(const vcla_attn_args* a, void* stream) {
         kern<<<grid, (NWM_) * 64, lds, s>>>(*a);                                                                     \
     }
     static const int vit_form = getenv("VCLA_ATTN_VIT") ? atoi(getenv("VCLA_ATTN_VIT")) : 2;   // 1 = register-staged form, 2 = direct-to-LDS pipelined form (257 tokens)
-    if (a->Tq == 257 && vit_form != 1 && abl_env == 0) {
+    const bool o16 = vcla_aligned(a->o, 16) && a->o_bs % 8 == 0 && a->o_hs % 8 == 0 && a->o_rs % 8 == 0;     // the DMA form stores O in 16-byte pieces
+    if (a->Tq == 257 && vit_form != 1 && abl_env == 0 && o16) {
         auto kern = attn_vit_dma_kernel;
         const size_t lds = (size_t)2 * 264 * 128 + 1024 + 4 * 66 * 4;
         static bool attr_set[VCLA_MAX_DEVICES] = {};
