@@ -177,12 +177,30 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
     t = model.config.text_config
     D, I, L = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"]
     P = model._packed
+    alg_bytes = 2 * I * D * 2
+    if M > 64:
+        # 65 - 256 decode rows run on the row-major 128 x 128 MFMA tiles (engine.hip llama_layer, gemm.hip launch_mfma): the weights are still
+        # streamed once per launch, so the bound quoted is HBM; the tile kernel at M = 256 is neither HBM- nor MFMA-bound (46 GF and 180 MB
+        # in ~90 us = 0.5 PF/s and 2 TB/s): every CU re-reads its share of the 2 MB activation panel, DESIGN.md section 5
+        x = torch.randn(M, D, device=model.device).to(torch.bfloat16)
+        out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
+        ws = torch.zeros(64 << 20, dtype=torch.uint8, device=model.device)
+
+        def run_tiles():
+            for l in range(L):
+                _lib.gemm(x, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, splitk_ws=ws,
+                          w_frag=P.get(f"llama.l{l}.wgu.f") if M <= 128 else None)      # M <= 128: the split-K panel kernel on the fragment-major copy
+        sec = _event_time(run_tiles, n_rep) / L
+        achieved = alg_bytes / sec / 1e9
+        return {"bound": "hbm", "kernel": (f"gemm_mfma_kernel<SWIGLU> (B={M} gate/up decode GEMM on 128x128 MFMA tiles, bf16)" if M > 128 else
+                                                 f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM, bf16)"), "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
+                "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L, "mfma_tflops": round(2.0 * M * 2 * I * D / sec / 1e12, 1)}
     if f"llama.l0.wgu.f" not in P:
         return None
     af = _lib.to_frag(torch.randn(M, D, device=model.device).to(torch.bfloat16))
     cf = torch.zeros(I // 32, (M + 15) // 16, 64, 8, dtype=torch.bfloat16, device=model.device)
     out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
-    alg_bytes = 2 * I * D * 2
 
     def run():
         for l in range(L):
@@ -259,7 +277,7 @@ def fp8_gemm_roofline(model, M: int = 8192, n_rep: int = 5):
             "alg_flops_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * nl}
 
 
-def step_rooflines(b1, b64, cfgd, fp8: bool, kv8: bool = False):
+def step_rooflines(b1, b64, cfgd, fp8: bool, kv8: bool = False, other=None):
     """Whole-step figures, so the line cannot quote only its best kernel: decode bytes per step = all LLaMA linear weights +
     lm_head read once (13.36 GB bf16 / 6.68 GB fp8, shared by the batch) + B * ctx * 512 KiB of KV cache (ctx = mean context
     over the decode steps); vision flops = 179.2 GF per image at 224 px (ViT 162.0 + resampler 16.64 + projection 0.54)."""
@@ -267,7 +285,7 @@ def step_rooflines(b1, b64, cfgd, fp8: bool, kv8: bool = False):
     w_bytes = 13.36e9 / (2 if fp8 else 1)
     ctx = T + (n_new + 1) / 2.0
     out = []
-    for tag, br in (("B=1", b1), ("B=64", b64)):
+    for tag, br in (("B=1", b1), ("B=64", b64)) + ((("B=%d" % other["batch_per_gpu"], other),) if other else ()):
         if not br:
             continue
         B = br["batch_per_gpu"]
@@ -596,7 +614,7 @@ def main():
         b64 = b64_res if b64_res else (main_res if B == 64 else None)
         rl = []
         if not args.fp8:
-            main_rl = gemv_roofline(model) if B == 1 else batch_decode_gemm_roofline(model, min(B, 64))
+            main_rl = gemv_roofline(model) if B == 1 else batch_decode_gemm_roofline(model, min(B, 256))
             res["roofline"] = main_rl
             rl.append(main_rl)
             if B == 1 and b64:
@@ -610,7 +628,7 @@ def main():
             res["roofline"] = r
             if r:
                 rl.append(r)
-        rl += step_rooflines(b1, b64, cfgd, args.fp8, bool(args.fp8_kv))
+        rl += step_rooflines(b1, b64, cfgd, args.fp8, bool(args.fp8_kv), main_res if B not in (1, 64) else None)
         res["rooflines"] = rl
         if not args.no_cpu_baseline and world == 1 and args.image_size == 224:   # the CPU baseline is reported by the N=1 run only
             try:
