@@ -47,3 +47,42 @@ def test_env_switch_keeps_parity(env):
     res = json.loads(line[len("RESULT "):])
     for tag, v in res.items():
         assert v["max"] <= 6e-2 and v["mean"] <= 1e-2 and v["ids_agree"], (env, tag, v)
+
+
+MACRO_CHILD = r"""
+import os, sys, torch
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd")):
+    sys.path.insert(0, p)
+from oracle import visualcla_oracle as O
+from tests.helpers import make_hip_model
+cfg = O.cfg_small()
+W = O.make_weights(cfg, seed=0)
+m = make_hip_model(cfg, W, torch.bfloat16)
+reqs = [tuple(t.cuda() if i else t.cuda().to(torch.bfloat16) for i, t in enumerate(O.make_inputs(cfg, B, 48))) for B in (3, 2)]   # resident request buffers (the graph key holds their addresses)
+first = {}
+for i in range(10):                      # two request shapes in strict alternation
+    px, ids, mask = reqs[i % 2]
+    t = m.generate(input_ids=ids, pixel_values=px, attention_mask=mask, max_new_tokens=4, do_sample=False, eos_token_id=None).cpu()
+    assert i % 2 not in first or torch.equal(t, first[i % 2]), i
+    first.setdefault(i % 2, t)
+    print(f"CALL {i}", file=sys.stderr, flush=True)
+print("MACRO_OK")
+"""
+
+
+def test_macro_graphs_keep_two_shapes_cached(tmp_path):
+    """the vision-stack / prefill graph cache holds TWO keys: a caller alternating between two request shapes (A, B, A, B, ...) replays both
+    after the warm-up instead of re-running eager + capture on every other call; results stay identical call to call"""
+    script = tmp_path / "macro_child.py"
+    script.write_text(MACRO_CHILD)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VCLA_") or k == "VCLA_LIB"}
+    env["VCLA_MACRO_GRAPH_DEBUG"] = "1"
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MACRO_OK" in r.stdout, r.stderr[-3000:]
+    calls = r.stderr.split("CALL ")
+    # each generate() = one vision-graph and one prefill-graph decision; from the 5th call on (A and B both seen twice) every decision is a replay
+    for i, chunk in enumerate(calls[:-1]):
+        lines = [ln for ln in chunk.splitlines() if "macro graph" in ln]
+        if i >= 4:
+            assert lines and all("replay" in ln for ln in lines), (i, lines)

@@ -143,9 +143,12 @@ struct vcla_ctx {
     // cached graphs of the vision stack and of the prefill (fixed launch sequences per shape: ~250 / ~290 launches that are host-bound
     // at B = 1).  Keyed on every pointer and shape the captured launches bake in; see run_macro.
     struct MacroGraph {
-        hipGraphExec_t exec = nullptr;
-        const void* key[8] = {};    // of the captured graph
-        const void* seen[8] = {};   // of the previous eager call
+        static constexpr int kSlots = 2;        // two shapes in rotation (e.g. forward(all_logits) and generate()'s prefill, or two batch sizes) both stay cached
+        hipGraphExec_t exec[kSlots] = {};
+        const void* key[kSlots][8] = {};        // of the captured graphs
+        unsigned long long used[kSlots] = {};   // last-use tick: the older slot is the one replaced
+        unsigned long long tick = 0;
+        const void* seen[8] = {};               // of the previous eager call
         int has_seen = 0;
     } vision_graph, prefill_graph;
     // cached decode graph
@@ -203,7 +206,8 @@ static void drop_graphs(vcla_ctx* ctx) {
     if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
     if (ctx->graph_exec_multi) { (void)hipGraphExecDestroy(ctx->graph_exec_multi); ctx->graph_exec_multi = nullptr; }
     for (vcla_ctx::MacroGraph* g : {&ctx->vision_graph, &ctx->prefill_graph}) {
-        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        for (int i = 0; i < vcla_ctx::MacroGraph::kSlots; ++i)
+            if (g->exec[i]) { (void)hipGraphExecDestroy(g->exec[i]); g->exec[i] = nullptr; }
         g->has_seen = 0;
     }
 }
@@ -521,14 +525,18 @@ static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipSt
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return run(s); }
     if (cap != hipStreamCaptureStatusNone) return run(s);
     static const int dbg = getenv("VCLA_MACRO_GRAPH_DEBUG") ? atoi(getenv("VCLA_MACRO_GRAPH_DEBUG")) : 0;
-    if (g.exec && memcmp(g.key, key, sizeof(g.key)) == 0) {
-        VCLA_CHECK_HIP(hipGraphLaunch(g.exec, s));
-        if (dbg) fprintf(stderr, "[vcla] macro graph %p: replay\n", (void*)&g);
-        return VCLA_OK;
+    constexpr int NS = vcla_ctx::MacroGraph::kSlots;
+    for (int i = 0; i < NS; ++i) {
+        if (g.exec[i] && memcmp(g.key[i], key, sizeof(g.key[i])) == 0) {
+            VCLA_CHECK_HIP(hipGraphLaunch(g.exec[i], s));
+            g.used[i] = ++g.tick;
+            if (dbg) fprintf(stderr, "[vcla] macro graph %p: replay (slot %d)\n", (void*)&g, i);
+            return VCLA_OK;
+        }
     }
-    if (dbg) fprintf(stderr, "[vcla] macro graph %p: eager call (%s)\n", (void*)&g, g.exec ? "key differs from the captured one" : "nothing captured yet");
-    // not the captured key: this call runs eagerly (which also leaves every per-device function attribute set); the graph is
-    // (re)captured behind it -- recorded, not executed -- when the key is the very first one or repeats the previous call's, so a
+    if (dbg) fprintf(stderr, "[vcla] macro graph %p: eager call (no captured graph has this key)\n", (void*)&g);
+    // not a captured key: this call runs eagerly (which also leaves every per-device function attribute set); the graph is
+    // captured behind it -- recorded, not executed -- when the key is the very first one or repeats the previous eager call's, so a
     // caller whose buffers move on every call never pays for captures it cannot reuse
     const bool repeat = g.has_seen && memcmp(g.seen, key, sizeof(g.seen)) == 0;
     const bool first = !g.has_seen;
@@ -541,7 +549,6 @@ static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipSt
     auto no_graph = [&](const char* what, hipError_t e) {
         if (dbg) fprintf(stderr, "[vcla] macro graph %p: %s failed (%s), staying eager\n", (void*)&g, what, hipGetErrorString(e));
         (void)hipGetLastError();
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
         return VCLA_OK;
     };
     hipGraph_t graph = nullptr;
@@ -557,9 +564,15 @@ static int run_macro(vcla_ctx::MacroGraph& g, const void* const (&key)[8], hipSt
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return no_graph("hipGraphInstantiate", e);
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    g.exec = exec;
-    memcpy(g.key, key, sizeof(g.key));
+    int victim = 0;
+    for (int i = 0; i < NS; ++i) {
+        if (!g.exec[i]) { victim = i; break; }
+        if (g.used[i] < g.used[victim]) victim = i;
+    }
+    if (g.exec[victim]) (void)hipGraphExecDestroy(g.exec[victim]);
+    g.exec[victim] = exec;
+    g.used[victim] = ++g.tick;
+    memcpy(g.key[victim], key, sizeof(g.key[victim]));
     return VCLA_OK;
 }
 
