@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int ROWS = NWM * 64 + 8;                                 // image rows incl. the padded piece of the last key
     constexpr int IMG = ROWS * 128;                                    // one operand image
     constexpr int TILE = 64 * 128;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];    // [K image][V image][last query row piece 1 KiB][NWM x 66 floats]
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];    // [K image][V image][last query row piece 1 KiB][NWM x 68 floats]
     unsigned char* ks_all = lds_all;
     unsigned char* vs_all = lds_all + IMG;
     unsigned char* qx_row = lds_all + 2 * IMG;
@@ -635,14 +635,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int prow = lane >> 3, pslot = lane & 7;
     auto k_chunk = [&](int row) { return pslot ^ ((row >> 1) & 7); };                                   // inverse of fa_k_off (an involution)
     auto v_chunk = [&](int row) { return ((((pslot >> 1) ^ (row >> 1)) & 3) << 1) + (pslot & 1); };    // inverse of fa_v_off's 32-byte block swizzle
-    // the wave's Q rows -> its 8 KiB staging area inside the images of key tiles 2 / 3 (waves 0, 1: K image; waves 2, 3: V image)
-    const unsigned qarea = lds_u + (wave < 2 ? 0 : IMG) + 2 * TILE + (wave & 1) * TILE;
+    // the wave's Q fragments (B port: lane (q = ql, g) holds Q[q][ks*32 + g*8 .. +8]) as register loads hipcc does not see: issued first,
+    // completed by the hand-counted wait in front of tile 0 (cdna_hip_programming.md section 5, form (ii): "=v" loads, then a wait statement
+    // naming every destination "+v" before the first consumer; the .s is audited for compiler moves of those registers in between)
+    u32x4_t qv[QT][KST];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = j * 8 + prow;
-        fa_dma16(qb + (int64_t)(qw + row) * a.q_rs + k_chunk(row) * 8, __builtin_amdgcn_readfirstlane(qarea + j * 1024));
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2) {
+            const bf16_t* qp = qb + (int64_t)(qw + qt * 16 + ql) * a.q_rs + s2 * 32 + g * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[qt][s2]) : "v"(qp) : "memory");
+        }
+    {   // the last key's K / V rows and the last query row: three padded 8-row pieces (rows clamped to the last one), one per wave (wave 3 repeats wave 2's)
+        const int row = NK - 1;
+        if (wave == 0) fa_dma16(kb + (int64_t)row * a.k_rs + k_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + (NK - 1) * 128));
+        else if (wave == 1) fa_dma16(vb + (int64_t)row * a.v_rs + v_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (NK - 1) * 128));
+        else fa_dma16(qb + (int64_t)row * a.q_rs + pslot * 8, __builtin_amdgcn_readfirstlane(lds_u + 2 * IMG));
     }
-    // key tiles: 16 pieces per tile (8 K + 8 V), 4 per wave
+    // key tiles: 16 pieces per tile (8 K + 8 V), 4 per wave, every tile requested up front in consumption order
     auto issue_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -654,27 +664,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     issue_tile(0);
     issue_tile(1);
-    {   // the last key's K / V rows and the last query row: three padded 8-row pieces (rows clamped to the last one), one per wave (wave 3 repeats wave 2's)
-        const int row = NK - 1;
-        if (wave == 0) fa_dma16(kb + (int64_t)row * a.k_rs + k_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + (NK - 1) * 128));
-        else if (wave == 1) fa_dma16(vb + (int64_t)row * a.v_rs + v_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (NK - 1) * 128));
-        else fa_dma16(qb + (int64_t)row * a.q_rs + pslot * 8, __builtin_amdgcn_readfirstlane(lds_u + 2 * IMG));
-    }
-    // ---- Q fragments out of the staging area (B port): lane (q = ql, g) holds Q[q][ks*32 + g*8 .. +8]
-    fa_vmcnt<9>();                                                     // the wave's own 8 Q pieces have landed (tiles 0, 1 and the last rows may not have)
-    FA_STAMP(1);
-    bf16x8_t qf[QT][KST];
-    {
-        const unsigned char* qa = lds_all + (wave < 2 ? 0 : IMG) + 2 * TILE + (wave & 1) * TILE;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int s = 0; s < KST; ++s) qf[qt][s] = *reinterpret_cast<const bf16x8_t*>(qa + fa_k_off<D>(qt * 16 + ql, s * 4 + g));
-    }
-    fa_lds_barrier();                                                  // every wave has its Q in registers: the staging areas may be overwritten
     issue_tile(2);
     issue_tile(3);
     FA_STAMP(2);
+    bf16x8_t qf[QT][KST];                   // filled from qv after the counted wait below
 
     f32x4_t o[QT][DT];
 #pragma unroll
@@ -752,18 +745,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // DMA queue of a wave now: [tile 0: 4][tile 1: 4][last rows: 1][tile 2: 4][tile 3: 4]; tile t is ready once nothing older than the
     // pieces behind it is outstanding (vmcnt retires in order) and every wave has said so
+    // VMEM queue of a wave: [Q: 8][last rows: 1][tile 0: 4][tile 1: 4][tile 2: 4][tile 3: 4]; vmcnt retires in order, so "at most 12 outstanding"
+    // means Q, the last rows and this wave's pieces of tile 0 have landed; every wave says so at the barrier
+    asm volatile("s_waitcnt vmcnt(12)"
+                 : "+v"(qv[0][0]), "+v"(qv[0][1]), "+v"(qv[1][0]), "+v"(qv[1][1]), "+v"(qv[2][0]), "+v"(qv[2][1]), "+v"(qv[3][0]), "+v"(qv[3][1])
+                 :: "memory");
+    FA_STAMP(1);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2) qf[qt][s2] = __builtin_bit_cast(bf16x8_t, qv[qt][s2]);
 #pragma unroll 1
     for (int tile = 0; tile < NWM; ++tile) {
-        if (tile == 0) fa_vmcnt<13>();
-        else if (tile == 1) fa_vmcnt<9>();
+        if (tile == 1) fa_vmcnt<8>();
         else if (tile == 2) fa_vmcnt<4>();
-        else fa_vmcnt<0>();
+        else if (tile == 3) fa_vmcnt<0>();
         fa_lds_barrier();
         if (tile == 0) FA_STAMP(3);
         tile_body(tile);
         FA_STAMP(4 + tile);
     }
-
     // ---- the last key (NK - 1) on the VALU, from LDS
     {
         bf16x8_t kx[KST];
@@ -811,38 +812,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             opk[qt][dt] = make_uint2(pack_bf2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
     }
     FA_STAMP(8);
-    // ---- last query row against this wave's 64 keys (wave 0: + the last key), on the VALU; partials merged by wave 0
+    // ---- the 257th query row against this wave's key tile, on the MFMAs: one 16-row q-tile whose every row IS the last row (row 0 is read
+    // out), 8 + 8 MFMAs on fragments this wave has just used -- the VALU form of the register-staged kernel above (a dot product per lane, 64
+    // readlane + LDS steps for P V) took 2.4 - 3.3 us of a 17 - 24 us workgroup (profiles/r04_vit_attn_timeline.txt).  Wave 0 adds the last key.
     {
-        bf16x8_t qx[8];
+        const unsigned char* ks = ks_all + wave * TILE;
+        const auto vbase = (__attribute__((address_space(3))) unsigned char*)lds_all + IMG + wave * TILE;
+        bf16x8_t qfx[KST];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) qx[c] = *reinterpret_cast<const bf16x8_t*>(qx_row + c * 16);      // broadcast reads
-        auto qdot = [&](int key) {
-            float d_ = 0.f;
+        for (int s2 = 0; s2 < KST; ++s2) qfx[s2] = *reinterpret_cast<const bf16x8_t*>(qx_row + (s2 * 4 + g) * 16);
+        f32x4_t sx[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bf16x8_t kc = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(key, c));
-                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 0, 1), __builtin_shufflevector(kc, kc, 0, 1), d_, false);
-                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 2, 3), __builtin_shufflevector(kc, kc, 2, 3), d_, false);
-                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 4, 5), __builtin_shufflevector(kc, kc, 4, 5), d_, false);
-                d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qx[c], qx[c], 6, 7), __builtin_shufflevector(kc, kc, 6, 7), d_, false);
+        for (int t = 0; t < 4; ++t) sx[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s2 * 4 + g));
+                sx[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfx[s2], sx[t], 0, 0, 0);
             }
-            return d_ * sl2;
-        };
-        const float sc = qdot(qw + lane);
-        const float sx = qdot(NK - 1);
-        float mw = wave_max(sc);
-        if (wave == 0) mw = fmaxf(mw, sx);
-        const float p = __builtin_amdgcn_exp2f(sc - mw);
-        const float px = wave == 0 ? __builtin_amdgcn_exp2f(sx - mw) : 0.f;
-        const float lw = wave_sum(p) + px;
-        float acc = px * bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(NK - 1, lane)));
-#pragma unroll 8
-        for (int kk = 0; kk < 64; ++kk) {
-            const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), kk));    // SGPR broadcast, no LDS round trip
-            acc = __builtin_fmaf(pk, bf2f(*reinterpret_cast<const bf16_t*>(vs_all + fa_v_off<D>(qw + kk, lane))), acc);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sx[t][r]);
+        mx *= sl2;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sk = 0.f;                                   // wave 0: the last query row against the last key
+        if (wave == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < KST; ++s2) {
+                const bf16x8_t kx = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(NK - 1, s2 * 4 + g));
+                sk = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qfx[s2], qfx[s2], 0, 1), __builtin_shufflevector(kx, kx, 0, 1), sk, false);
+                sk = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qfx[s2], qfx[s2], 2, 3), __builtin_shufflevector(kx, kx, 2, 3), sk, false);
+                sk = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qfx[s2], qfx[s2], 4, 5), __builtin_shufflevector(kx, kx, 4, 5), sk, false);
+                sk = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qfx[s2], qfx[s2], 6, 7), __builtin_shufflevector(kx, kx, 6, 7), sk, false);
+            }
+            sk += __shfl_xor(sk, 16, 64);
+            sk += __shfl_xor(sk, 32, 64);
+            sk *= sl2;
+            mx = fmaxf(mx, sk);
         }
-        part[wave * 66 + lane] = acc;
-        if (lane == 0) { part[wave * 66 + 64] = mw; part[wave * 66 + 65] = lw; }
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[t][r], sl2, -mx));
+                pv[t * 4 + r] = pp;
+                ps += pp;
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        bf16x8_t pfx[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 u;
+            u.x = pack_bf2(pv[(2 * s2) * 4 + 0], pv[(2 * s2) * 4 + 1]);
+            u.y = pack_bf2(pv[(2 * s2) * 4 + 2], pv[(2 * s2) * 4 + 3]);
+            u.z = pack_bf2(pv[(2 * s2 + 1) * 4 + 0], pv[(2 * s2 + 1) * 4 + 1]);
+            u.w = pack_bf2(pv[(2 * s2 + 1) * 4 + 2], pv[(2 * s2 + 1) * 4 + 3]);
+            pfx[s2] = __builtin_bit_cast(bf16x8_t, u);
+        }
+        f32x4_t ox[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            ox[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int kr = g * 4 + (ql >> 2), dc = dt * 16 + (ql & 3) * 4;
+                const fa_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s2) * 16 + kr, dc)));
+                const fa_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s2 + 1) * 16 + kr, dc)));
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfx[s2], ox[dt], 0, 0, 0);
+            }
+        }
+        if (wave == 0) {                                  // fold the last key into wave 0's partial
+            const float pk = __builtin_amdgcn_exp2f(sk - mx);
+            ps += pk;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const uint2 vx = *reinterpret_cast<const uint2*>(vs_all + fa_v_off<D>(NK - 1, dt * 16 + g * 4));
+                ox[dt][0] = __builtin_fmaf(pk, __uint_as_float(vx.x << 16), ox[dt][0]);
+                ox[dt][1] = __builtin_fmaf(pk, __uint_as_float(vx.x & 0xffff0000u), ox[dt][1]);
+                ox[dt][2] = __builtin_fmaf(pk, __uint_as_float(vx.y << 16), ox[dt][2]);
+                ox[dt][3] = __builtin_fmaf(pk, __uint_as_float(vx.y & 0xffff0000u), ox[dt][3]);
+            }
+        }
+        if (ql == 0) {                                    // lanes (0, g) hold row 0: d = dt*16 + g*4 + r
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(part + wave * 68 + dt * 16 + g * 4) = ox[dt];
+            if (g == 0) { part[wave * 68 + 64] = mx; part[wave * 68 + 65] = ps; }
+        }
     }
     FA_STAMP(9);
     __syncthreads();                      // every wave is done with K / V: the images are free
@@ -870,13 +933,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wave == 0) {
         float m = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < NWM; ++w) m = fmaxf(m, part[w * 66 + 64]);
+        for (int w = 0; w < NWM; ++w) m = fmaxf(m, part[w * 68 + 64]);
         float l = 0.f, acc = 0.f;
 #pragma unroll
         for (int w = 0; w < NWM; ++w) {
-            const float f = exp2f(part[w * 66 + 64] - m);
-            l = __builtin_fmaf(part[w * 66 + 65], f, l);
-            acc = __builtin_fmaf(part[w * 66 + lane], f, acc);
+            const float f = exp2f(part[w * 68 + 64] - m);
+            l = __builtin_fmaf(part[w * 68 + 65], f, l);
+            acc = __builtin_fmaf(part[w * 68 + lane], f, acc);
         }
         ob[(int64_t)(NK - 1) * a.o_rs + lane] = f2bf(acc / l);
     }
@@ -910,7 +973,7 @@ int vcla_attention_vit(const vcla_attn_args* a, void* stream) {
     const bool o16 = vcla_aligned(a->o, 16) && a->o_bs % 8 == 0 && a->o_hs % 8 == 0 && a->o_rs % 8 == 0;     // the DMA form stores O in 16-byte pieces
     if (a->Tq == 257 && vit_form != 1 && abl_env == 0 && o16) {
         auto kern = attn_vit_dma_kernel;
-        const size_t lds = (size_t)2 * 264 * 128 + 1024 + 4 * 66 * 4;
+        const size_t lds = (size_t)2 * 264 * 128 + 1024 + 4 * 68 * 4;
         static bool attr_set[VCLA_MAX_DEVICES] = {};
         const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set);
         if (rc_) return rc_;
