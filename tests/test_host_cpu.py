@@ -333,3 +333,62 @@ def test_no_compute_kernel_uses_scratch():
                     bad.append((name.group(1), int(priv.group(1))))
     assert n_kernels > 300, n_kernels
     assert not bad, f"kernels with a private segment (spills / scratch arrays): {bad}"
+
+
+def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
+    """attn_vit_dma_kernel loads its Q fragments with inline-asm `global_load_dwordx4` that hipcc does not count (the hand-counted vmcnt in
+    front of key tile 0 completes them together with the LDS-DMA pieces).  hipcc treats an asm load's destination as written at the end of
+    the statement, so nothing but register allocation keeps it from copying / spilling / reusing those registers before the data lands
+    (cdna_hip_programming.md section 5).  This test audits the SHIPPED code object: between the 8 loads and the `s_waitcnt vmcnt(12)` no
+    instruction may name one of their 32 destination registers."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(ROOT, "visual-chinese-llama-alpaca_amd", "visualcla", "libvisualcla_hip.so")
+    if not (os.path.exists(so) and all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump", "llvm-readelf"))):
+        pytest.skip("library not built or ROCm LLVM tools absent")
+    sym = "_Z19attn_vit_dma_kernel14vcla_attn_args"
+    with tempfile.TemporaryDirectory() as td:
+        fb = os.path.join(td, "fat.bin")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", so])
+        data = open(fb, "rb").read()
+        offs = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+        body = None
+        for k, o in enumerate(offs):
+            bf, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"b{k}.co")
+            with open(bf, "wb") as f:
+                f.write(data[o:offs[k + 1] if k + 1 < len(offs) else len(data)])
+            subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={bf}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            if sym not in subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout:
+                continue
+            dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--mcpu=gfx950", f"--disassemble-symbols={sym}", co], capture_output=True, text=True, check=True).stdout
+            body = dis[dis.index(f"<{sym}>:"):]
+            break
+    assert body is not None, "attn_vit_dma_kernel not found in the library"
+    lines = [ln.split("//")[0] for ln in body.splitlines()[1:]]
+    loads, first, wait = [], None, None
+    for i, ln in enumerate(lines):
+        m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off\s*$", ln.strip())
+        if m and wait is None:
+            loads.append((int(m.group(1)), int(m.group(2))))
+            first = i if first is None else first
+        if wait is None and re.search(r"s_waitcnt vmcnt\(12\)", ln):
+            wait = i
+    assert len(loads) == 8 and wait is not None and first < wait, (loads, first, wait)
+    regs = {r for a, b in loads for r in range(a, b + 1)}
+    assert len(regs) == 32
+    touched = []
+    for ln in lines[first:wait]:
+        t = ln.strip()
+        if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off\s*$", t):
+            continue                                     # the loads themselves (their ADDRESS registers are checked by the other loads' lines below)
+        used = set()
+        for m in re.finditer(r"\bv(\d+)\b", t):
+            used.add(int(m.group(1)))
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
+            used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        if used & regs:
+            touched.append(t)
+    assert not touched, "instructions naming a Q destination register before the counted wait:\n" + "\n".join(touched[:10])
