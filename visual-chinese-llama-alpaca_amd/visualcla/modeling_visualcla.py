@@ -458,36 +458,61 @@ class VisualCLAModel:
             taps["image_embeds"] = out
         return out
 
-    def _find_image_slots(self, input_ids: torch.Tensor, Q: int, need_img_token: bool) -> torch.Tensor:
-        """Per sample: index of <img> (-1 = no image slot).  Mirrors modeling_visualcla.py:296-302 (forward:
-        also requires an <img_token>) / :362-367 (generate); raises the same ValueError on a malformed slot."""
-        s_id, e_id, t_id = self._special_ids()
+    def _check_request(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], Q: int, for_generate: bool):
+        """Every data-dependent validation of a request in ONE host synchronisation (round 3 paid three to four device -> host round trips in
+        front of each forward / generate): ids inside the vocabulary, image slots well-formed (modeling_visualcla.py:296-302 / :362-367),
+        the attention mask all ones (-> no key mask at all) or free of masked positions between visible ones (see _key_mask).
+        Q = 0: no image.  Returns (img_pos int32 [B] or None, extended mask or None when nothing is masked).  Raises the reference's ValueErrors."""
         B, T = input_ids.shape
-        is_start = input_ids == s_id
-        has = is_start.any(dim=1)
-        if need_img_token:
-            has = has & (input_ids == t_id).any(dim=1)
-        p0 = is_start.int().argmax(dim=1)
-        endpos = p0 + Q + 1
-        ok = (endpos < T) & (input_ids.gather(1, endpos.clamp(max=T - 1)[:, None])[:, 0] == e_id)
-        if bool((has & ~ok).any()):
+        V = self.config.text_config["vocab_size"]
+        dev = input_ids.device
+        zero = torch.zeros((), dtype=torch.bool, device=dev)
+        bad_vocab = ((input_ids < 0) | (input_ids >= V)).any()
+        img_pos, bad_slot = None, zero
+        slotted = Q > 0 and not self.image_at_head
+        if slotted:
+            s_id, e_id, t_id = self._special_ids()
+            is_start = input_ids == s_id
+            has = is_start.any(dim=1)
+            if not for_generate:                                  # forward also asks for an <img_token> (:297); generate only for the <img> (:363)
+                has = has & (input_ids == t_id).any(dim=1)
+            p0 = is_start.int().argmax(dim=1)
+            endpos = p0 + Q + 1
+            ok = (endpos < T) & (input_ids.gather(1, endpos.clamp(max=T - 1)[:, None])[:, 0] == e_id)
+            bad_slot = (has & ~ok).any()
+            img_pos = torch.where(has, p0, torch.full_like(p0, -1)).to(torch.int32)
+        am, all_ones, gap = None, ~zero, zero
+        if attention_mask is not None:
+            am = attention_mask.to(dev)
+            if Q > 0 and self.image_at_head:                      # the reference prepends the image columns (:308-310)
+                am = torch.cat([torch.ones(B, Q, dtype=am.dtype, device=dev), am], dim=1)
+            vis = am != 0
+            all_ones = vis.all()
+            masked_after_visible = (~vis) & (vis.int().cummax(dim=1).values > 0)
+            gap = (vis & (masked_after_visible.int().cummax(dim=1).values > 0)).any()
+        flags = torch.stack([bad_vocab, bad_slot, all_ones, gap]).tolist()       # the one synchronisation
+        if flags[0]:
+            raise ValueError("input_ids contain ids outside the vocabulary")
+        if flags[1]:
             raise ValueError(f"Num of patch ({Q}) is not equal to the length of pre-filled image patch tokens.")
-        return torch.where(has, p0, torch.full_like(p0, -1)).to(torch.int32)
+        if flags[3]:
+            # RoPE positions here are absolute sequence indices.  For padding at either END of a row that is what the reference
+            # computes too (a contiguous left pad shifts a row's positions by a constant, which RoPE attention is invariant to); zeros
+            # BETWEEN visible tokens -- only reachable through image_at_head=True with a left-padded text mask,
+            # models/visualcla/modeling_visualcla.py:307-312 -- would put the text at other relative distances from the image tokens
+            # than HF's cumsum(attention_mask) positions do: refuse instead of computing something else.
+            raise ValueError("attention_mask has masked positions between visible tokens (image_at_head=True with left padding?); "
+                             "only left- or right-padded masks are supported")
+        return img_pos, (None if (am is None or flags[2]) else am)
 
-    def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], for_generate: bool, _persistent: bool = False):
-        """-> (inputs_embeds [B, T', D], attention-mask extension length).  Handles both placements."""
+    def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], img_pos: Optional[torch.Tensor], _persistent: bool = False):
+        """-> (inputs_embeds [B, T', D], number of positions the image added in front of the text mask).  Handles both placements;
+        `img_pos` comes from _check_request (slot placement) and is ignored for image_at_head."""
         lib = _lib.load()
         t = self.config.text_config
-        if input_ids.dim() != 2:
-            raise ValueError(f"input_ids must be [batch, seq], got {tuple(input_ids.shape)}")
-        input_ids = input_ids.long()               # the kernel reads int64 ids
         B, T = input_ids.shape
         V, D = t["vocab_size"], t["hidden_size"]
-        if image_embeds is not None and image_embeds.shape[0] != B:
-            raise ValueError(f"pixel_values hold {image_embeds.shape[0]} images for {B} prompts")
-        if bool(((input_ids < 0) | (input_ids >= V)).any()):
-            raise ValueError("input_ids contain ids outside the vocabulary")
-        Q, img_pos, extra = 0, None, 0
+        Q, extra = 0, 0
         ids = input_ids
         if image_embeds is not None:
             Q = image_embeds.shape[1]
@@ -497,8 +522,8 @@ class VisualCLAModel:
                 ids = torch.cat([ids[:, :2], filler, ids[:, 2:]], dim=1)
                 img_pos = torch.full((B,), 1, dtype=torch.int32, device=ids.device)
                 extra = Q
-            else:
-                img_pos = self._find_image_slots(ids, Q, need_img_token=not for_generate)
+        else:
+            img_pos = None
         ids = ids.contiguous()
         Tn = ids.shape[1]
         out = self._typed_buf("gen_embeds", (B, Tn, D), self._dtype) if _persistent else torch.empty(B, Tn, D, dtype=self._dtype, device=self._device)
@@ -507,6 +532,16 @@ class VisualCLAModel:
                                              _lib.ptr(image_embeds), _lib.ptr(img_pos), out.data_ptr(), B, Tn, Q, D, V,
                                              _lib.dtype_code(self._dtype), _lib.stream_ptr()))
         return out, extra
+
+    def _prepare_ids(self, input_ids, pixel_values):
+        """shape checks that need no device data: -> int64 ids on the device"""
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [batch, seq], got {tuple(input_ids.shape)}")
+        if pixel_values is not None and pixel_values.shape[0] != input_ids.shape[0]:
+            raise ValueError(f"pixel_values hold {pixel_values.shape[0]} images for {input_ids.shape[0]} prompts")
+        return input_ids.to(self._device).long()               # the kernel reads int64 ids
 
     def _new_cache(self, B: int, ctx_max: int, _persistent: bool = False) -> VclaCache:
         t = self.config.text_config
@@ -517,27 +552,13 @@ class VisualCLAModel:
         kv = self._typed_buf("gen_kv", shape, kdt) if _persistent else torch.empty(*shape, dtype=kdt, device=self._device)
         return VclaCache(kv, 0, ctx_max)
 
-    def _key_mask(self, attention_mask: Optional[torch.Tensor], B: int, T: int, ctx_max: int, extra: int):
-        """int32 [B, ctx_max] or None when nothing is masked (1 = attend)."""
-        if attention_mask is None:
+    def _key_mask(self, am: Optional[torch.Tensor], B: int, T: int, ctx_max: int):
+        """int32 [B, ctx_max] (1 = attend), or None when nothing is masked.  `am` = the validated mask of _check_request (image columns
+        already prepended for image_at_head; None = all ones)."""
+        if am is None:
             return None
-        am = attention_mask.to(self._device)
-        if extra:
-            am = torch.cat([torch.ones(B, extra, dtype=am.dtype, device=am.device), am], dim=1)
         if am.shape[1] != T:
             raise ValueError(f"attention_mask length {am.shape[1]} does not match sequence length {T}")
-        if bool(am.bool().all()):
-            return None
-        # RoPE positions here are absolute sequence indices.  For padding at either END of a row that is what the reference
-        # computes too (a contiguous left pad shifts a row's positions by a constant, which RoPE attention is invariant to); zeros
-        # BETWEEN visible tokens -- only reachable through image_at_head=True with a left-padded text mask,
-        # models/visualcla/modeling_visualcla.py:307-312 -- would put the text at other relative distances from the image tokens
-        # than HF's cumsum(attention_mask) positions do: refuse instead of computing something else.
-        vis = am != 0
-        gap = (~vis) & (vis.int().cummax(dim=1).values > 0)            # a masked position after a visible one ...
-        if bool((vis & (gap.int().cummax(dim=1).values > 0)).any()):   # ... followed by another visible one
-            raise ValueError("attention_mask has masked positions between visible tokens (image_at_head=True with left padding?); "
-                             "only left- or right-padded masks are supported")
         km = torch.ones(B, ctx_max, dtype=torch.int32, device=self._device)
         km[:, :T] = am.to(torch.int32)
         return km
@@ -579,12 +600,12 @@ class VisualCLAModel:
         """Same contract as the reference forward (modeling_visualcla.py:264-330): logits [B, T, V] (fp32),
         optional loss, KV cache handle.  `position_ids` is accepted and ignored, as in the reference (:269 vs :321-328)."""
         from transformers.modeling_outputs import CausalLMOutputWithPast
-        if input_ids is None:
-            raise ValueError("input_ids is required")
-        input_ids = input_ids.to(self._device)
+        input_ids = self._prepare_ids(input_ids, pixel_values)
         B = input_ids.shape[0]
+        Q = self.config.visual_resampler_config["num_query_tokens"] if pixel_values is not None else 0
+        img_pos, am = self._check_request(input_ids, attention_mask, Q, for_generate=False)      # one host sync; raises before any kernel runs
         img = self.embed_images(pixel_values, taps) if pixel_values is not None else None
-        embeds, extra = self._embed(input_ids, img, for_generate=False)
+        embeds, extra = self._embed(input_ids, img, img_pos)
         if taps is not None:
             taps["spliced_embeds"] = embeds
         T = embeds.shape[1]
@@ -595,7 +616,7 @@ class VisualCLAModel:
         if cache is None:
             cap = T if not use_cache else min(self.config.text_config["max_position_embeddings"], (T + 512 + 63) // 64 * 64)
             cache = self._new_cache(B, cap)
-        key_mask = self._key_mask(attention_mask, B, cache.length + T, cache.ctx_max, extra) if attention_mask is not None else None
+        key_mask = self._key_mask(am, B, cache.length + T, cache.ctx_max)
         logits = self._prefill(embeds, cache, key_mask, all_logits=True, taps=taps)
         loss = None
         if labels is not None:
@@ -698,7 +719,7 @@ class VisualCLAModel:
             from transformers.generation.logits_process import PrefixConstrainedLogitsProcessor
             logits_processor = list(logits_processor or []) + [PrefixConstrainedLogitsProcessor(prefix_allowed_tokens_fn, num_beams=1)]
         t = self.config.text_config
-        input_ids = input_ids.to(self._device)
+        input_ids = self._prepare_ids(input_ids, pixel_values)
         B = input_ids.shape[0]
         if use_graph is None:
             use_graph = os.environ.get("VCLA_DECODE_GRAPH", "1") != "0"
@@ -723,8 +744,10 @@ class VisualCLAModel:
         t = self.config.text_config
         B = input_ids.shape[0]
         persistent = bool(use_graph)
+        Q = self.config.visual_resampler_config["num_query_tokens"] if pixel_values is not None else 0
+        img_pos, am = self._check_request(input_ids, attention_mask, Q, for_generate=True)       # one host sync; raises before any kernel runs
         img = self.embed_images(pixel_values, _persistent=persistent) if pixel_values is not None else None
-        embeds, extra = self._embed(input_ids, img, for_generate=True, _persistent=persistent)
+        embeds, extra = self._embed(input_ids, img, img_pos, _persistent=persistent)
         T = embeds.shape[1]
         max_pos = t["max_position_embeddings"]
         if gc.max_new_tokens is not None:
@@ -736,7 +759,7 @@ class VisualCLAModel:
             raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
         ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
         cache = self._new_cache(B, ctx_max, _persistent=persistent)
-        key_mask = self._key_mask(attention_mask, B, T, ctx_max, extra)
+        key_mask = self._key_mask(am, B, T, ctx_max)
         logits = self._prefill(embeds, cache, key_mask, all_logits=False, _persistent=persistent)
 
         eos = self._eos_list(gc)
