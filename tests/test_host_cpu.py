@@ -392,3 +392,16 @@ def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
         if used & regs:
             touched.append(t)
     assert not touched, "instructions naming a Q destination register before the counted wait:\n" + "\n".join(touched[:10])
+
+
+def test_hf_cpu_baseline_child_runs_and_reports_the_contract_fields():
+    """bench.py's cpu_baseline leg = oracle/hf_cpu_baseline.py in a child process (transformers' CLIPVisionModel + LlamaForCausalLM.generate with
+    the restated resampler between them).  Run it at the small geometry: one JSON line with value / unit / cores / kind / sample."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "hf_cpu_baseline.py"), "--geometry", "small", "--prompt-len", "48", "--tokens", "4",
+                        "--sweep", "1,2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["kind"] == "hf+port-resampler" and d["unit"] == "tokens/s" and d["value"] > 0 and d["cores"] in (1, 2)
+    assert set(d["thread_sweep_decode_s_per_token"]) == {"1", "2"} and "LlamaForCausalLM.generate" in d["sample"]
