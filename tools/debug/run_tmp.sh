@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "dstream" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -p no:cacheprovider -k "batch64 or batch_rows or single_token" 2>&1 | tail -2
+VCLA_BENCH_MS=64,32 python tools/bench_kernels.py dstream 2>&1 | grep -E "lm_head"
+for i in 1 2; do timeout 600 python bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --steps-c4 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['images_per_sec'], d['breakdown_ms'])"; done

@@ -261,6 +261,15 @@ __global__ __launch_bounds__(DS_WAVES * 64) void gemm_dstream_kernel(vcla_gemm_a
                 ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);   // ring depth 2 (a third stage next to 96 accumulators spills 21 registers)
                 continue;
             }
+            if constexpr (sizeof(OutT) == 4) {
+                // fp32 output = the lm_head (49958 columns: 12 - 13 tiles per workgroup).  Every chunk is one more pass over the activation panel
+                // (512 KB per CU at M = 64, ~9 us by the intake model): chunks of 6 tiles while 6 remain -> 2 - 3 passes instead of 4
+                if (t_end - c0 >= 6) {
+                    ds_chunk<EPI, OutT, MT, 6, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
+                    c0 += 6 - NTW;
+                    continue;
+                }
+            }
             if (nt == 4) ds_chunk<EPI, OutT, MT, 4, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 3) ds_chunk<EPI, OutT, MT, 3, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
             else if (nt == 2) ds_chunk<EPI, OutT, MT, 2, FP8>(c, c0, slab, rstd_s, c0 == t_beg);
