@@ -44,7 +44,11 @@ dist.destroy_process_group()
 
 
 def test_rccl_world1_gathers_device_int64_tokens(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port (a fixed one may be taken on a shared box)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     script = tmp_path / "rccl_child.py"
     script.write_text(CHILD)
