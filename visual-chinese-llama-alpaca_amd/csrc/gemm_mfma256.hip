@@ -191,17 +191,34 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
                         accx[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * (WMC < 0 ? 0 : WMC)], afx, accx[0][0], 0, 0, 0);
                         accx[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * (WMC < 0 ? 0 : WMC) + 1], afx, accx[0][1], 0, 0, 0);
                     }
-                    if (SGB) {
-                        // issue order: 6 fragment reads (4 W + 2 A), then 4 MFMAs per further A read, so every ds_read runs two fragments
-                        // ahead of the MFMAs that consume it (XR: a 13th read, 34 MFMAs)
-                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                }
+                if (SGB) {
+                    // issue order, ONE pipeline over both 32-deep halves of the K step (round 4; was one pattern per half): 6 fragment reads (4 W + 2 A),
+                    // then 4 MFMAs per further A read so that every ds_read runs two fragments ahead of the MFMAs that consume it (XR: a 13th read, 34
+                    // MFMAs), and the first 6 reads of the SECOND half ride under the last MFMAs of the first instead of opening a second read ramp:
+                    // +1 - 3 % on the LLaMA prefill shapes, nothing on the 257-row ViT tiles; 8 reads of lead are no better (profiles/r04_gemm256_sgb_ab.txt)
+                    constexpr int LEAD = 6;
+                    constexpr int NR = 12 + XR, NM = 32 + 2 * XR;          // reads / MFMAs per half
+                    __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0);
     #pragma unroll
-                        for (int i = 0; i < 6 + XR; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, XR ? 6 : 8, 0);
+                    for (int i = 0; i < NR - LEAD; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
+                    // first half: 4 (NR - LEAD) MFMAs issued; the second half's first LEAD reads ride under the rest, spread evenly
+                    constexpr int REST = NM - 4 * (NR - LEAD), PER = REST / LEAD;
+    #pragma unroll
+                    for (int i = 0; i < LEAD; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    if constexpr (REST - PER * LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST - PER * LEAD, 0);
+    #pragma unroll
+                    for (int i = 0; i < NR - LEAD; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NM - 4 * (NR - LEAD), 0);
                 }
                 asm volatile("" ::: "memory");                       // the fragment reads stay on this side of the next barrier
             }
