@@ -86,3 +86,37 @@ def test_macro_graphs_keep_two_shapes_cached(tmp_path):
         lines = [ln for ln in chunk.splitlines() if "macro graph" in ln]
         if i >= 4:
             assert lines and all("replay" in ln for ln in lines), (i, lines)
+
+
+VIT_CHILD = r"""
+import math, os, sys, torch
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd")):
+    sys.path.insert(0, p)
+from visualcla import _lib
+B, H, T, D = 9, 16, 257, 64
+g = torch.Generator().manual_seed(5)
+q, k, v = (torch.randn(B, H, T, D, generator=g).to(torch.bfloat16) for _ in range(3))
+s = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(D)
+ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, T, H * D)
+out = torch.empty(B, T, H * D, dtype=torch.bfloat16, device="cuda:0")
+for fk in (3, 0):          # forced, and the automatic dispatch (B * H = 144 >= 128)
+    out.fill_(7.0)
+    _lib.attention(q.cuda(), k.cuda(), v.cuda(), 1 / math.sqrt(D), causal=False, out=out, force_kernel=fk)
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-2, (fk, err)
+print("VIT_OK")
+"""
+
+
+@pytest.mark.parametrize("form", ["0", "1", "2"])
+def test_vit_attention_forms_by_env(tmp_path, form):
+    """VCLA_ATTN_VIT = 0 (tile-by-tile kernel), 1 (register-staged whole-sequence form), 2 (direct-to-LDS pipelined form, the default): each
+    against the fp32 reference on a 257-token ViT shape, forced and through the automatic dispatch"""
+    script = tmp_path / "vit_child.py"
+    script.write_text(VIT_CHILD)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VCLA_") or k == "VCLA_LIB"}
+    env["VCLA_ATTN_VIT"] = form
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "VIT_OK" in r.stdout, r.stderr[-2000:]
