@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import visualcla_oracle as O
-from tests.helpers import to_vcla_config
+from tests.helpers import stub_tokenizer, to_vcla_config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -405,3 +405,50 @@ def test_hf_cpu_baseline_child_runs_and_reports_the_contract_fields():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["kind"] == "hf+port-resampler" and d["unit"] == "tokens/s" and d["value"] > 0 and d["cores"] in (1, 2)
     assert set(d["thread_sweep_decode_s_per_token"]) == {"1", "2"} and "LlamaForCausalLM.generate" in d["sample"]
+
+
+def test_check_request_validates_in_one_pass_on_cpu():
+    """VisualCLAModel._check_request (every data-dependent validation of a request, one host synchronisation) is plain tensor logic: exercised on
+    the CPU through the oracle-backed stand-in of tests/repl_stub (no HIP involved).  Precedence and messages follow the reference: vocabulary
+    first, then the image slot (modeling_visualcla.py:300-302 / :366-367), then the mask."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "repl_stub"))
+    from oracle_backed import OracleBackedModel
+    cfg = O.cfg_tiny()
+    m = OracleBackedModel(to_vcla_config(cfg), {})
+    m.tokenizer = stub_tokenizer(cfg)
+    m.image_at_head = False
+    Q = cfg.resampler.num_query_tokens
+    px, ids, mask = O.make_inputs(cfg, 2, 24)
+    pos, am = m._check_request(ids, mask, Q, for_generate=False)
+    p0 = int((ids[0] == cfg.img_start_token_id).nonzero()[0])
+    assert pos.dtype == torch.int32 and pos.tolist() == [p0, p0] and am is None            # all-ones mask -> no key mask at all
+    lp = mask.clone(); lp[1, :3] = 0
+    pos, am = m._check_request(ids, lp, Q, for_generate=True)
+    assert am is not None and torch.equal(am, lp)
+    # a row without <img>: -1 (its embeds pass through); forward additionally asks for an <img_token>
+    no_slot = ids.clone(); no_slot[1] = torch.randint(3, 300, (24,))
+    assert m._check_request(no_slot, mask, Q, for_generate=True)[0].tolist() == [p0, -1]
+    only_start = no_slot.clone(); only_start[1, 2] = cfg.img_start_token_id               # <img> without the slot: generate must refuse, forward lets it pass
+    assert m._check_request(only_start, mask, Q, for_generate=False)[0].tolist() == [p0, -1]
+    with pytest.raises(ValueError, match="Num of patch"):
+        m._check_request(only_start, mask, Q, for_generate=True)
+    bad = ids.clone(); bad[0, p0 + Q + 1] = 5
+    with pytest.raises(ValueError, match="Num of patch"):
+        m._check_request(bad, mask, Q, for_generate=False)
+    oov = bad.clone(); oov[1, 0] = cfg.text.vocab_size                                     # vocabulary error wins over the slot error
+    with pytest.raises(ValueError, match="outside the vocabulary"):
+        m._check_request(oov, mask, Q, for_generate=False)
+    hole = mask.clone(); hole[0, 5] = 0
+    with pytest.raises(ValueError, match="between visible tokens"):
+        m._check_request(ids, hole, Q, for_generate=False)
+    right = mask.clone(); right[1, 20:] = 0
+    assert m._check_request(ids, right, Q, for_generate=False)[1] is not None              # right padding: accepted
+    # image_at_head: the image columns are prepended to the mask (modeling_visualcla.py:308-310); a left-padded text mask then has an interior hole
+    m.image_at_head = True
+    txt = torch.randint(3, 300, (2, 10)); tm = torch.ones_like(txt)
+    pos, am = m._check_request(txt, tm, Q, for_generate=False)
+    assert pos is None and am is None
+    tm[1, :2] = 0
+    with pytest.raises(ValueError, match="between visible tokens"):
+        m._check_request(txt, tm, Q, for_generate=False)
+    assert m._check_request(txt, tm, 0, for_generate=False)[1] is not None                 # text-only (no image): plain left padding is fine
