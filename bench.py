@@ -186,14 +186,17 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
         out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
         ws = torch.zeros(64 << 20, dtype=torch.uint8, device=model.device)
 
+        use_frag = M <= 128 and f"llama.l0.wgu.f" in P      # M <= 128 with the fragment-major copy: the split-K panel kernel; else the row-major MFMA tiles
+
         def run_tiles():
             for l in range(L):
                 _lib.gemm(x, P[f"llama.l{l}.wgu"], 2 * I, out=out, epilogue=_lib.EPI_SWIGLU, splitk_ws=ws,
-                          w_frag=P.get(f"llama.l{l}.wgu.f") if M <= 128 else None)      # M <= 128: the split-K panel kernel on the fragment-major copy
+                          w_frag=P[f"llama.l{l}.wgu.f"] if use_frag else None)
         sec = _event_time(run_tiles, n_rep) / L
         achieved = alg_bytes / sec / 1e9
-        return {"bound": "hbm", "kernel": (f"gemm_mfma_kernel<SWIGLU> (B={M} gate/up decode GEMM on 128x128 MFMA tiles, bf16)" if M > 128 else
-                                                 f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM, bf16)"), "achieved": round(achieved, 1),
+        return {"bound": "hbm", "kernel": (f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM on the fragment-major copy, bf16)" if use_frag else
+                                                 f"vcla_gemm default dispatch on the row-major weights (B={M} gate/up decode GEMM: 128x128 MFMA tiles / panel kernel, bf16)"),
+                "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L, "mfma_tflops": round(2.0 * M * 2 * I * D / sec / 1e12, 1)}
     if f"llama.l0.wgu.f" not in P:

@@ -124,7 +124,10 @@ typedef struct vcla_gemm_args {
                              8 panel MFMA (M <= 128, activations shared through LDS, split-K over workgroups);
                              9 streaming MFMA (M <= 64, needs A_frag + W_frag / W_q8_frag: every CU streams an equal share of W over
                                the FULL K, no split-K partials, no LDS in the main loop);
-                             10 fp8 MFMA 256x256x128 direct-to-LDS (needs A_q8 + a_scale + W_q8 + w_scale) */
+                             10 fp8 MFMA 256x256x128 direct-to-LDS (needs A_q8 + a_scale + W_q8 + w_scale);
+                             11 ring MFMA (the default for 129 <= M <= 256: full-K tiles fed by an LDS-DMA ring, row-major bf16 A, bf16 W or
+                               fp8 W_q8 + w_scale, epilogue NONE / SWIGLU; tile chosen per shape), 12 / 13 / 14 = the same with the
+                               256x96 / 128x96 / 64x64 tile forced */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */

@@ -238,6 +238,25 @@ def edge_cases(mods):
             lg = model(input_ids=mids, pixel_values=px, attention_mask=mask, return_dict=True).logits
         put("mixed_rows", input_ids=mids, attention_mask=mask, logits=lg,
             generated=_greedy(model, 4, input_ids=mids, pixel_values=px, attention_mask=mask))
+        # (7) masks with zeros BETWEEN visible tokens, forward only (:307-328 never forwards position_ids: HF rotates by arange positions whatever
+        #     the mask says): image_at_head=True with a left-padded text mask = [1] * Q ++ [0, 0, 0, 1, ...], and a text-only prompt with a hole
+        pids = torch.cat([torch.tensor([[1, cfg.img_start_token_id, cfg.img_end_token_id]] * 2), torch.randint(3, 300, (2, 9), generator=g)], dim=1)
+        pids, pmask = _left_pad(pids, torch.ones_like(pids), 1, 3)
+        model.image_at_head = True
+        plabels = pids.clone()               # the reference's image_at_head forward needs labels (:315 indexes them unconditionally)
+        plabels[:, 0] = -100
+        plabels[1, :4] = -100
+        with torch.no_grad():
+            o = model(input_ids=pids, pixel_values=px, attention_mask=pmask, labels=plabels, return_dict=True)
+        model.image_at_head = False
+        put("head_leftpad", input_ids=pids, attention_mask=pmask, labels=plabels, logits=o.logits, loss=o.loss.reshape(1))
+        hole = torch.randint(3, 300, (2, 10), generator=g)
+        hmask2 = torch.ones_like(hole)
+        hmask2[0, 4] = 0
+        hmask2[1, 2:4] = 0
+        with torch.no_grad():
+            lg = model(input_ids=hole, attention_mask=hmask2, return_dict=True).logits
+        put("text_hole", input_ids=hole, attention_mask=hmask2, logits=lg)
     return out
 
 

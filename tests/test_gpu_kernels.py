@@ -197,6 +197,70 @@ def test_gemm_tile257(lib, M, N, K, epi, fk):
     _cmp(f"gemm_tile257_f32[{M}x{N}x{K},epi{epi},k{fk}]", f32, _gemm_ref(a, w, bias, epi, None), atol=2e-4, rtol=2e-5)
 
 
+RING_SHAPES = [
+    # M, N, K, epi -- the four LLaMA-7B decode GEMMs at 129 - 256 rows (tiles 128 x 96, 64 x 64, 256 x 96, 64 x 64) + lm_head, then ragged / tiny shapes
+    (256, 12288, 4096, 0), (256, 4096, 4096, 0), (256, 22016, 4096, 3), (256, 4096, 11008, 0), (200, 12288, 4096, 0), (129, 4096, 4096, 0),
+    (193, 22016, 4096, 3), (255, 4096, 11008, 0), (256, 49958, 4096, 0),
+    (130, 200, 192, 0), (256, 96, 64, 0), (131, 1000, 128, 3), (250, 333, 704, 0), (256, 5120, 13824, 0), (144, 64, 4096, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,epi", RING_SHAPES)
+def test_gemm_ring(lib, M, N, K, epi, cfg):
+    """kernel 11 (gemm_ring.hip: full-K tiles fed by an LDS-DMA ring, 129 - 256 rows): every row and column against the fp32 reference with bias,
+    in-place residual, SwiGLU, ragged M / N, fp32 output; cfg = 0 is the kernel's own tile choice (force_kernel 11), 1 / 2 / 3 force the 256 x 96 /
+    128 x 96 / 64 x 64 tile (force_kernel 12 / 13 / 14)."""
+    if cfg > 1 and epi == 3:
+        pytest.skip("SwiGLU exists on the 256 x 96 tile only")
+    if cfg and (N > 30000 or (M, N, K) in ((200, 12288, 4096), (193, 22016, 4096), (255, 4096, 11008))):
+        pytest.skip("forced tiles: one instance of each LLaMA shape is enough")
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M * 1000 + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf16r(torch.randn(N, generator=g) * 0.1)
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g))
+    ref = _gemm_ref(a, w, bias, epi, res)
+    wp = _pack(w)
+    fk = 11 + cfg
+    xd = res.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=xd, out=xd, epilogue=epi, force_kernel=fk)
+    _cmp(f"gemm_ring[{M}x{N}x{K},epi{epi},cfg{cfg}]", xd, ref, atol=3e-3 if K > 2048 else 2e-3, rtol=8e-3)
+    again = res.to(DEV, torch.bfloat16)
+    lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=again, out=again, epilogue=epi, force_kernel=fk)
+    assert torch.equal(xd, again)                    # fixed summation order: the same bits on every run
+    if epi == 0:
+        f32 = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), force_kernel=fk, out_f32=True)
+        _cmp(f"gemm_ring_f32[{M}x{N}x{K},cfg{cfg}]", f32, _gemm_ref(a, w, bias, 0, None), atol=3e-4, rtol=2e-5)
+    if cfg == 0:                                     # the dispatch picks this kernel for 129 - 256 rows
+        auto = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, bias=bias.to(DEV), residual=res.to(DEV, torch.bfloat16), epilogue=epi)
+        assert torch.equal(auto, xd)
+
+
+@pytest.mark.parametrize("M,N,K,epi,f32out", [(256, 12288, 4096, 0, False), (256, 4096, 4096, 0, False), (256, 22016, 4096, 3, False), (256, 4096, 11008, 0, False),
+                                              (160, 22016, 4096, 3, False), (129, 4096, 11008, 0, False), (256, 49958, 4096, 0, True), (130, 200, 192, 0, False),
+                                              (250, 352, 704, 3, False)])
+def test_gemm_ring_fp8_weights(lib, M, N, K, epi, f32out):
+    """W8A16 at 129 - 256 rows (BASELINE configs[4], decode batches of its N = 1 leg): the ring kernel stages the e4m3 rows as they are and widens them
+    in registers -- EXACTLY the function of the dequantised weights (e4m3 -> bf16 is exact, fp32 accumulate, row scale in the epilogue), the same
+    function the M = 1 GEMV and the M <= 128 panel kernel compute"""
+    from visualcla.weights import quantize_fp8_rows, dequantize_fp8_rows
+    g = torch.Generator().manual_seed(M + N + K + epi + 3)
+    a = bf16r(torch.randn(M, K, generator=g))
+    wp = _pack(bf16r(torch.randn(N, K, generator=g) * 0.05))
+    q, sc = quantize_fp8_rows(wp)
+    wdq = dequantize_fp8_rows(q, sc)[:N].cpu()
+    n_out = N // 2 if epi == 3 else N
+    res = None if f32out else bf16r(torch.randn(M, n_out, generator=g))
+    ref = _gemm_ref(a, wdq, None, epi, res)
+    got = lib.gemm(a.to(DEV, torch.bfloat16), wp, N, residual=None if res is None else res.to(DEV, torch.bfloat16), epilogue=epi, out_f32=f32out,
+                   w_q8=q, w_scale=sc, force_kernel=11)
+    _cmp(f"gemm_ring_fp8[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-4 if f32out else 4e-3, rtol=2e-5 if f32out else 8e-3)
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "gemv"])
 def test_gemm_f32_output_and_identity(lib, kernel):
     """A = I (asymmetric W) catches operand/row-column swaps; fp32 output keeps the full accumulator."""
@@ -390,6 +454,36 @@ def test_causal_lm_loss_matches_the_hf_formula(lib, B, T, V):
         assert math.isnan(float(got))
     none = lib.causal_lm_loss(lg_d, torch.full((B, T), -100, dtype=torch.int64, device=DEV))
     assert math.isnan(float(none))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_causal_lm_loss_propagates_non_finite_logits(lib, bad):
+    """A NaN or +inf logit in a SUPERVISED row makes the loss nan, as torch's cross_entropy / HF's ForCausalLMLoss do (round 4 clamped such a
+    row to 0 = "perfect prediction"); in an ignored row it changes nothing; a -inf logit is an ordinary masked class (finite loss unless it is
+    the target, then +inf)."""
+    B, T, V = 2, 6, 300
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, T, V, generator=g) * 2.0
+    labels = torch.randint(0, V, (B, T), generator=g)
+    labels[:, 0] = -100
+    labels[1, 4] = -100                                   # -> row (1, 3) has no target
+    clean = float(lib.causal_lm_loss(logits.to(DEV), labels.to(DEV)))
+    poisoned = logits.clone()
+    poisoned[0, 2, 17] = bad                              # row (0, 2) is scored against labels[0, 3]
+    want = torch.nn.functional.cross_entropy(poisoned[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+    got = float(lib.causal_lm_loss(poisoned.to(DEV), labels.to(DEV)))
+    assert math.isnan(float(want)) and math.isnan(got), (float(want), got)
+    ignored = logits.clone()
+    ignored[1, 3, 5] = bad                                # a row without a target: not read at all
+    ignored[0, T - 1, 9] = bad                            # the last position never has one
+    assert float(lib.causal_lm_loss(ignored.to(DEV), labels.to(DEV))) == clean
+    masked = logits.clone()
+    masked[0, 2, (int(labels[0, 3]) + 1) % V] = float("-inf")
+    want = float(torch.nn.functional.cross_entropy(masked[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100))
+    got = float(lib.causal_lm_loss(masked.to(DEV), labels.to(DEV)))
+    assert math.isfinite(got) and abs(got - want) <= 2e-5 * max(1.0, abs(want))
+    masked[0, 2, int(labels[0, 3])] = float("-inf")
+    assert float(lib.causal_lm_loss(masked.to(DEV), labels.to(DEV))) == float("inf")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

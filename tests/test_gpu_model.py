@@ -286,10 +286,32 @@ def test_edge_row_without_an_image_slot_matches_reference(dtype, golden_dir):
         assert torch.equal(toks, e["generated"]), (toks, e["generated"])
 
 
-def test_masks_with_interior_zeros_are_refused():
-    """image_at_head=True + a left-padded text mask = [1]*Q ++ [0..0, 1..1] (modeling_visualcla.py:307-312): zeros between visible
-    tokens would give other relative RoPE distances than HF's cumsum positions -> ValueError, not a silently different result.
-    Left- and right-padded masks stay accepted."""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_masks_with_interior_zeros_forward_matches_reference(dtype, golden_dir):
+    """Zeros BETWEEN visible tokens in `forward`: the reference never forwards position_ids (modeling_visualcla.py:321-328), HF rotates by arange
+    positions and the mask only removes keys -- computed exactly so here (round 4 refused it).  Fixtures made by the reference itself:
+    image_at_head=True with a left-padded text mask = [1] * Q ++ [0, 0, 0, 1, ...] (logits and loss), and a text-only prompt with holes."""
+    e = _edge(golden_dir, "head_leftpad")
+    cfg, m, px, _, _ = _edge_model(dtype)
+    m.image_at_head = True
+    ids, mask, labels = e["input_ids"], e["attention_mask"], e["labels"]
+    out = m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
+    _check_logits("head_leftpad", out.logits, e["logits"], dtype)
+    d = abs(float(out.loss) - float(e["loss"][0]))
+    _report(f"edge head_leftpad [{dtype}]: loss {float(out.loss):.6f} vs reference {float(e['loss'][0]):.6f}")
+    assert d <= (1e-4 if dtype == torch.float32 else 1e-2), d
+    m.image_at_head = False
+    e = _edge(golden_dir, "text_hole")
+    ids, mask = e["input_ids"], e["attention_mask"]
+    out = m.forward(input_ids=ids.cuda(), attention_mask=mask.cuda())
+    _check_logits("text_hole", out.logits, e["logits"], dtype)
+
+
+def test_masks_with_interior_zeros_are_refused_by_generate_only():
+    """image_at_head=True + a left-padded text mask = [1]*Q ++ [0..0, 1..1] (modeling_visualcla.py:372-377): in `generate` the transformers
+    versions the reference pins derive cumsum(mask) positions, which zeros between visible tokens would make differ from the absolute
+    positions used here -> ValueError, not a silently different result.  `forward` computes it (test above); left- and right-padded masks
+    are accepted everywhere."""
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)
     px, _, _ = O.make_inputs(cfg, 2, 24)
@@ -298,19 +320,25 @@ def test_masks_with_interior_zeros_are_refused():
     mask[1, :3] = 0
     m = make_hip_model(cfg, W, torch.float32)
     m.image_at_head = True
-    with pytest.raises(ValueError, match="between visible tokens"):
-        m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda())
+    m.forward(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda())
     with pytest.raises(ValueError, match="between visible tokens"):
         m.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), max_new_tokens=2, do_sample=False)
     m.image_at_head = False
     txt_mask = torch.ones_like(ids)
     txt_mask[0, 4] = 0                                   # a hole in a text-only prompt
+    m.forward(input_ids=ids.cuda(), attention_mask=txt_mask.cuda())
     with pytest.raises(ValueError, match="between visible tokens"):
-        m.forward(input_ids=ids.cuda(), attention_mask=txt_mask.cuda())
+        m.generate(input_ids=ids.cuda(), attention_mask=txt_mask.cuda(), max_new_tokens=2, do_sample=False)
     right = torch.ones_like(ids)
     right[1, 7:] = 0                                     # right padding: fine
     m.forward(input_ids=ids.cuda(), attention_mask=right.cuda())
     m.forward(input_ids=ids.cuda(), attention_mask=mask.cuda())      # left padding without the image prefix: fine
+    lab = ids.clone()
+    lab[0, 3] = cfg.text.vocab_size                      # labels are validated with the request, before any kernel runs
+    with pytest.raises(ValueError, match="labels contain ids outside"):
+        m.forward(input_ids=ids.cuda(), attention_mask=right.cuda(), labels=lab.cuda())
+    with pytest.raises(ValueError, match="do not match"):
+        m.forward(input_ids=ids.cuda(), attention_mask=right.cuda(), labels=lab[:, :-1].cuda())
 
 
 @pytest.mark.parametrize("B", [2, 16, 64])

@@ -439,8 +439,14 @@ def test_check_request_validates_in_one_pass_on_cpu():
     with pytest.raises(ValueError, match="outside the vocabulary"):
         m._check_request(oov, mask, Q, for_generate=False)
     hole = mask.clone(); hole[0, 5] = 0
-    with pytest.raises(ValueError, match="between visible tokens"):
-        m._check_request(ids, hole, Q, for_generate=False)
+    with pytest.raises(ValueError, match="between visible tokens"):                        # generate: HF's mask-derived positions would differ -> refused
+        m._check_request(ids, hole, Q, for_generate=True)
+    assert torch.equal(m._check_request(ids, hole, Q, for_generate=False)[1], hole)        # forward: arange positions, the mask only removes keys (as the reference)
+    lab = ids.clone(); lab[:, :5] = -100
+    m._check_request(ids, mask, Q, for_generate=False, labels=lab)
+    lab[1, 7] = cfg.text.vocab_size
+    with pytest.raises(ValueError, match="labels contain ids outside"):
+        m._check_request(ids, mask, Q, for_generate=False, labels=lab)
     right = mask.clone(); right[1, 20:] = 0
     assert m._check_request(ids, right, Q, for_generate=False)[1] is not None              # right padding: accepted
     # image_at_head: the image columns are prepended to the mask (modeling_visualcla.py:308-310); a left-padded text mask then has an interior hole
@@ -450,5 +456,7 @@ def test_check_request_validates_in_one_pass_on_cpu():
     assert pos is None and am is None
     tm[1, :2] = 0
     with pytest.raises(ValueError, match="between visible tokens"):
-        m._check_request(txt, tm, Q, for_generate=False)
+        m._check_request(txt, tm, Q, for_generate=True)
+    am = m._check_request(txt, tm, Q, for_generate=False)[1]
+    assert am.shape == (2, Q + 10) and bool(am[:, :Q].all()) and am[1, Q:Q + 2].tolist() == [0, 0]
     assert m._check_request(txt, tm, 0, for_generate=False)[1] is not None                 # text-only (no image): plain left padding is fine

@@ -186,3 +186,24 @@ def test_edge_row_without_an_image_slot(golden_dir):
     assert torch.allclose(O.visualcla_forward(ids, px, mask, W, cfg), e["logits"], atol=2e-5)
     toks = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=e["generated"].shape[1])
     assert torch.equal(toks, e["generated"])
+
+
+def test_edge_masks_with_zeros_between_visible_tokens(golden_dir):
+    """forward only: the reference never forwards position_ids (modeling_visualcla.py:321-328), so HF rotates by arange positions and the
+    mask only removes keys.  (a) image_at_head=True with a left-padded text mask = [1] * Q ++ [0, 0, 0, 1, ...] (:308-310; the reference
+    needs labels in that mode, :315), (b) a text-only prompt with holes.  No query row is left without a visible key here, so every
+    position's logits are compared."""
+    e = _edge(golden_dir, "head_leftpad")
+    cfg, W, px, _, _ = _tiny_inputs()
+    ids, mask, labels = e["input_ids"], e["attention_mask"], e["labels"]
+    Q = cfg.resampler.num_query_tokens
+    full = torch.cat([torch.ones(2, Q, dtype=mask.dtype), mask], dim=1)
+    vis = full.bool()
+    assert bool(((~vis) & (vis.int().cummax(dim=1).values > 0)).any())          # zeros after a visible column: the case under test
+    logits, loss = O.visualcla_forward(ids, px, mask, W, cfg, image_at_head=True, labels=labels)
+    assert logits.shape == e["logits"].shape and torch.allclose(logits, e["logits"], atol=2e-5)
+    assert abs(float(loss) - float(e["loss"][0])) <= 1e-5
+    e = _edge(golden_dir, "text_hole")
+    ids, mask = e["input_ids"], e["attention_mask"]
+    assert int(mask[0, 4]) == 0 and int(mask[0, 3]) == 1 and int(mask[0, 5]) == 1
+    assert torch.allclose(O.visualcla_forward(ids, None, mask, W, cfg), e["logits"], atol=2e-5)

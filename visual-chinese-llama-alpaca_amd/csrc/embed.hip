@@ -306,7 +306,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_rows_kernel(const float* __rest
     const int row = blockIdx.x, b = row / T, t = row % T;
     const int64_t tgt = t + 1 < T ? labels[(int64_t)b * T + t + 1] : ignore_index;
     if (tgt == ignore_index || tgt < 0 || tgt >= V) {          // (out-of-range targets are refused by the host wrapper; skipped here to stay in bounds)
-        if (threadIdx.x == 0) row_loss[row] = -1.0f;            // marker: not counted (a real row loss is >= 0)
+        if (threadIdx.x == 0) row_loss[row] = -1.0f;            // marker: not counted (a real row loss is >= 0, +inf or NaN)
         return;
     }
     const float* lr = logits + (int64_t)row * ld_row;
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(CE_THREADS) void ce_rows_kernel(const float* __rest
     float sum = 0.f;
     for (int j = threadIdx.x; j < V; j += CE_THREADS) sum += expf(lr[j] - mx);
     sum = block_sum_256(sum, red + 4);
-    if (threadIdx.x == 0) row_loss[row] = fmaxf(mx + logf(sum) - lr[tgt], 0.0f);
+    // a NaN / +inf logit anywhere in the row makes `sum` NaN (expf(NaN - mx), expf(inf - inf)) and the row loss NaN, as torch's log_softmax does:
+    // the clamp below must not swallow it (fmaxf(NaN, 0) = 0 would count the row as a perfect prediction)
+    const float l = mx + logf(sum) - lr[tgt];
+    if (threadIdx.x == 0) row_loss[row] = l < 0.f ? 0.f : l;
 }
 __global__ __launch_bounds__(CE_THREADS) void ce_mean_kernel(const float* __restrict__ row_loss, int rows, float* __restrict__ out) {
     __shared__ float s_sum[CE_THREADS];
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_mean_kernel(const float* __rest
     int cnt = 0;
     for (int r = threadIdx.x; r < rows; r += CE_THREADS) {
         const float v = row_loss[r];
-        if (v >= 0.f) { acc += v; ++cnt; }
+        if (v != -1.0f) { acc += v; ++cnt; }          // -1.0f = "no target" marker (exactly; real row losses are >= 0, +inf or NaN -- all of which count)
     }
     s_sum[threadIdx.x] = acc;
     s_cnt[threadIdx.x] = cnt;

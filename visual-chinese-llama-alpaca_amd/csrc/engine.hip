@@ -203,6 +203,12 @@ extern "C" int vcla_ctx_create(const vcla_model_cfg* cfg, vcla_ctx** out) {
 
 // The cached graphs bake in weight pointers: registering a tensor (LoRA swap, adding fp8 copies) makes all of them stale.
 static void drop_graphs(vcla_ctx* ctx) {
+    // An exec may still be executing (its last hipGraphLaunch is asynchronous) and HIP does not promise deferred destruction on every ROCm
+    // version: drain the device first.  Only when there is something to destroy -- registering the tensors of a fresh context costs nothing.
+    bool any = ctx->graph_exec || ctx->graph_exec_multi;
+    for (const vcla_ctx::MacroGraph* g : {&ctx->vision_graph, &ctx->prefill_graph})
+        for (int i = 0; i < vcla_ctx::MacroGraph::kSlots; ++i) any = any || g->exec[i];
+    if (any && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
     if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
     if (ctx->graph_exec_multi) { (void)hipGraphExecDestroy(ctx->graph_exec_multi); ctx->graph_exec_multi = nullptr; }
     for (vcla_ctx::MacroGraph* g : {&ctx->vision_graph, &ctx->prefill_graph}) {
@@ -468,6 +474,14 @@ static int gemm(vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const 
         int rc = vcla_quant_fp8_rows(A, lda, ctx->run.q8_ws, ctx->run.q8s_ws, M, K, s);
         if (rc) return rc;
         a.A = nullptr; a.A_q8 = ctx->run.q8_ws; a.a_scale = ctx->run.q8s_ws; a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 10;
+        return vcla_gemm(&a, ctx->c.act_dtype, s);
+    }
+    if (wv && M > 128 && M <= 256 && ctx->run.decode_step && wv->q8 && wv->s8 && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0 &&
+        (epi == VCLA_EPI_NONE || (epi == VCLA_EPI_SWIGLU && !out_f32))) {
+        // BASELINE configs[4], decode batches of 129 - 256 sequences (its N = 1 leg, B = 256): the ring kernel stages the fp8 rows as they are and
+        // widens them in registers -- the SAME W8A16 function of the dequantised weights the M <= 128 decode kernels compute, whatever the batch
+        // size (round 4 read the bf16 matrices here); lm_head included (fp32 logits).
+        a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 11;
         return vcla_gemm(&a, ctx->c.act_dtype, s);
     }
     if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)

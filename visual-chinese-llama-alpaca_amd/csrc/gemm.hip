@@ -23,6 +23,7 @@ int vcla_gemm_dstream_launch(const vcla_gemm_args* a, hipStream_t s);   // gemm_
 #include "gemm_tiles.h"
 int vcla_gemm_mfma256_launch(const vcla_gemm_args* a, bool sgb, hipStream_t s);     // gemm_mfma256.hip (kernels 4 / 5)
 int vcla_gemm_mfma256_fp8_launch(const vcla_gemm_args* a, hipStream_t s);          // gemm_mfma256.hip (kernel 10)
+int vcla_gemm_ring_launch(const vcla_gemm_args* a, hipStream_t s);                 // gemm_ring.hip (kernel 11)
 bool vcla_gemm_tile257_ok(const vcla_gemm_args* a);                                // 257-row tiles apply (M = B * 257)
 
 // =================================================================== MFMA kernel
@@ -1200,6 +1201,8 @@ static int dispatch_epi(const vcla_gemm_args* a, int dtype, int kernel, hipStrea
         return vcla_gemm_dstream_launch(a, s);
     } else if (kernel == 10) {
         return vcla_gemm_mfma256_fp8_launch(a, s);
+    } else if (kernel >= 11 && kernel <= 14) {
+        return vcla_gemm_ring_launch(a, s);
     } else if (kernel == 2 || kernel == 6) {
         if (kernel == 2 && gemv1_applicable(a, dtype)) return launch_gemv1_auto(a, s);
         if (dtype == VCLA_F32) return launch_gemv<float, float, EPI>(a, s);
@@ -1287,14 +1290,24 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                 }
             }
             kernel = prefer_256(a) ? 4 : 1;
+            // 129 - 256 rows (a LLaMA decode batch of that many sequences, a prefill of that many prompt rows): the intake-bound ring kernel
+            // (gemm_ring.hip) -- full K per tile, no split-K partials.  VCLA_RING=0: the round-4 dispatch (128 x 128 tiles + K slices).
+            static const int ring_env = getenv("VCLA_RING") ? atoi(getenv("VCLA_RING")) : 1;
+            if (ring_env && a->M <= 256 && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && a->c_group_rows <= 0) kernel = 11;
         }
     }
-    VCLA_REQUIRE(kernel >= 1 && kernel <= 10, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(kernel >= 1 && kernel <= 14, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
+    VCLA_REQUIRE(!(kernel > 12 && kernel <= 14 && a->epilogue == VCLA_EPI_SWIGLU), VCLA_ERR_BAD_ARG, "gemm: the ring kernel's SwiGLU tile is 256 x 96 (force_kernel 11 / 12)");
     if (kernel == 10) {
         VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_q8 && a->a_scale && a->W_q8 && a->w_scale && vcla_aligned(a->A_q8, 16) && vcla_aligned(a->W_q8, 16) &&
                          a->K % 128 == 0, VCLA_ERR_BAD_ARG, "gemm: the fp8 MFMA kernel needs A_q8 + a_scale, W_q8 + w_scale (16-byte aligned) and K %% 128 == 0 (K=%d)", a->K);
         VCLA_REQUIRE(a->C && !a->C_frag && !a->A_frag && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
                      "gemm: the fp8 MFMA kernel writes a row-major C and takes no fused norms");
+    } else if (kernel >= 11) {
+        VCLA_REQUIRE(dtype == VCLA_BF16 && a->A && a->C && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && !a->C_frag &&
+                         !a->A_frag && !a->A_q8 && !a->a_scale && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->c_frag_gamma, VCLA_ERR_BAD_ARG,
+                     "gemm: the ring kernel takes a row-major bf16 A, epilogue NONE (bf16 / fp32 C) or SWIGLU (bf16 C), no fused norms");
+        VCLA_REQUIRE(!a->W_q8 || (a->w_scale && vcla_aligned(a->W_q8, 16)), VCLA_ERR_BAD_ARG, "gemm: the ring kernel's fp8 weights need W_q8 (16-byte aligned) + w_scale");
     } else if (kernel == 9) {
         VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_frag && vcla_aligned(a->A_frag, 16) && a->M <= 64 && (a->W_frag || a->W_q8_frag), VCLA_ERR_BAD_ARG,
                      "gemm: the streaming kernel needs bf16, A_frag, M <= 64 (got %d) and W_frag or W_q8_frag", a->M);
@@ -1316,7 +1329,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->A_q8 && !a->a_scale, VCLA_ERR_BAD_ARG,
                      "gemm: A_frag / C_frag / deferred-norm fields belong to the streaming kernel (9), A_q8 / a_scale to the fp8 MFMA kernel (10)");
     }
-    VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
+    VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8 || kernel >= 11) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
     VCLA_REQUIRE(!((kernel == 2 || kernel == 6) && a->M > 8), VCLA_ERR_BAD_SHAPE, "gemm: GEMV kernel needs M <= 8 (got %d)", a->M);
     VCLA_REQUIRE(!a->norm_gamma || kernel == 2 || kernel == 6, VCLA_ERR_BAD_ARG, "gemm: the fused RMSNorm prologue exists only in the GEMV kernel (M <= 8)");
@@ -1326,8 +1339,8 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights need w_scale and bf16 activations");
     VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
-    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9 || kernel == 10, VCLA_ERR_BAD_ARG,
-                 "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8) and the M <= 128 panel kernel (needs W_q8_frag)");
+    VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9 || kernel == 10 || kernel >= 11, VCLA_ERR_BAD_ARG,
+                 "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8), the M <= 128 panel kernel (needs W_q8_frag) and the ring kernel (W_q8)");
     VCLA_REQUIRE(!(kernel == 2 && a->w_scale) || (a->W_q8 && gemv1_applicable(a, dtype)), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 GEMV needs W_q8, M = 1, bf16, epilogue NONE/SWIGLU");
     VCLA_REQUIRE(!(kernel == 8 && a->w_scale) || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: fp8 panel kernel needs W_q8_frag");

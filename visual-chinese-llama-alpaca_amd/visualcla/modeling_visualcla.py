@@ -458,16 +458,22 @@ class VisualCLAModel:
             taps["image_embeds"] = out
         return out
 
-    def _check_request(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], Q: int, for_generate: bool):
+    def _check_request(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], Q: int, for_generate: bool,
+                       labels: Optional[torch.Tensor] = None):
         """Every data-dependent validation of a request in ONE host synchronisation (round 3 paid three to four device -> host round trips in
         front of each forward / generate): ids inside the vocabulary, image slots well-formed (modeling_visualcla.py:296-302 / :362-367),
-        the attention mask all ones (-> no key mask at all) or free of masked positions between visible ones (see _key_mask).
+        the attention mask all ones (-> no key mask at all) or -- generate only -- free of masked positions between visible ones, `labels`
+        (forward; already extended for image_at_head) inside the vocabulary or -100.
         Q = 0: no image.  Returns (img_pos int32 [B] or None, extended mask or None when nothing is masked).  Raises the reference's ValueErrors."""
         B, T = input_ids.shape
         V = self.config.text_config["vocab_size"]
         dev = input_ids.device
         zero = torch.zeros((), dtype=torch.bool, device=dev)
         bad_vocab = ((input_ids < 0) | (input_ids >= V)).any()
+        bad_label = zero
+        if labels is not None:
+            lab = labels.to(dev)
+            bad_label = ((lab != -100) & ((lab < 0) | (lab >= V))).any()
         img_pos, bad_slot = None, zero
         slotted = Q > 0 and not self.image_at_head
         if slotted:
@@ -490,19 +496,23 @@ class VisualCLAModel:
             all_ones = vis.all()
             masked_after_visible = (~vis) & (vis.int().cummax(dim=1).values > 0)
             gap = (vis & (masked_after_visible.int().cummax(dim=1).values > 0)).any()
-        flags = torch.stack([bad_vocab, bad_slot, all_ones, gap]).tolist()       # the one synchronisation
+        flags = torch.stack([bad_vocab, bad_slot, all_ones, gap, bad_label]).tolist()       # the one synchronisation
         if flags[0]:
             raise ValueError("input_ids contain ids outside the vocabulary")
         if flags[1]:
             raise ValueError(f"Num of patch ({Q}) is not equal to the length of pre-filled image patch tokens.")
-        if flags[3]:
-            # RoPE positions here are absolute sequence indices.  For padding at either END of a row that is what the reference
-            # computes too (a contiguous left pad shifts a row's positions by a constant, which RoPE attention is invariant to); zeros
-            # BETWEEN visible tokens -- only reachable through image_at_head=True with a left-padded text mask,
-            # models/visualcla/modeling_visualcla.py:307-312 -- would put the text at other relative distances from the image tokens
-            # than HF's cumsum(attention_mask) positions do: refuse instead of computing something else.
+        if flags[4]:
+            raise ValueError("labels contain ids outside the vocabulary")
+        if flags[3] and for_generate:
+            # RoPE positions here are absolute sequence indices.  In `forward` that IS the reference's arithmetic for every mask: it never
+            # forwards position_ids (models/visualcla/modeling_visualcla.py:321-328), so HF rotates by arange positions and the mask only
+            # removes keys (fixtures head_leftpad / text_hole of tests/golden/ref_edge_cases.npz).  `generate` under the transformers versions
+            # the reference pins (>= 4.29) derives cumsum(attention_mask) - 1 positions instead: for padding at either END of a row that
+            # is a constant shift per row (RoPE attention is invariant to it), but zeros BETWEEN visible tokens -- only reachable through
+            # image_at_head=True with a left-padded text mask, :307-312 / :372-377 -- would put the text at other relative distances from
+            # the image tokens: refuse instead of computing something else.
             raise ValueError("attention_mask has masked positions between visible tokens (image_at_head=True with left padding?); "
-                             "only left- or right-padded masks are supported")
+                             "generate() supports left- or right-padded masks only")
         return img_pos, (None if (am is None or flags[2]) else am)
 
     def _embed(self, input_ids: torch.Tensor, image_embeds: Optional[torch.Tensor], img_pos: Optional[torch.Tensor], _persistent: bool = False):
@@ -603,15 +613,20 @@ class VisualCLAModel:
         input_ids = self._prepare_ids(input_ids, pixel_values)
         B = input_ids.shape[0]
         Q = self.config.visual_resampler_config["num_query_tokens"] if pixel_values is not None else 0
-        img_pos, am = self._check_request(input_ids, attention_mask, Q, for_generate=False)      # one host sync; raises before any kernel runs
+        n_extra = Q if self.image_at_head else 0        # positions the image adds in front of the text (modeling_visualcla.py:290-291)
+        if labels is not None:
+            if n_extra:                                 # the reference's placement: Q ignore-labels after position 0 (:313-315)
+                labels = torch.cat([labels[:, :1], torch.full((B, n_extra), -100, dtype=labels.dtype, device=labels.device),
+                                    labels[:, 1:]], dim=1)
+            if tuple(labels.shape) != (B, input_ids.shape[1] + n_extra):
+                raise ValueError(f"labels of shape {tuple(labels.shape)} do not match the {input_ids.shape[1] + n_extra}-position sequence")
+        # one host sync (ids, slots, mask, labels); raises before any kernel runs
+        img_pos, am = self._check_request(input_ids, attention_mask, Q, for_generate=False, labels=labels)
         img = self.embed_images(pixel_values, taps) if pixel_values is not None else None
         embeds, extra = self._embed(input_ids, img, img_pos)
         if taps is not None:
             taps["spliced_embeds"] = embeds
         T = embeds.shape[1]
-        if labels is not None and extra:
-            labels = torch.cat([labels[:, :1], torch.full((B, extra), -100, dtype=labels.dtype, device=labels.device),
-                                labels[:, 1:]], dim=1)
         cache = past_key_values
         if cache is None:
             cap = T if not use_cache else min(self.config.text_config["max_position_embeddings"], (T + 512 + 63) // 64 * 64)
@@ -620,11 +635,7 @@ class VisualCLAModel:
         logits = self._prefill(embeds, cache, key_mask, all_logits=True, taps=taps)
         loss = None
         if labels is not None:
-            lab = labels.to(self._device)
-            if lab.shape != (B, T):
-                raise ValueError(f"labels of shape {tuple(lab.shape)} do not match the {T}-position sequence")
-            if bool(((lab != -100) & ((lab < 0) | (lab >= logits.shape[-1]))).any()):
-                raise ValueError("labels contain ids outside the vocabulary")
+            lab = labels.to(self._device)                  # shape and vocabulary range were checked up front (_check_request)
             with torch.cuda.device(self._device):
                 loss = _lib.causal_lm_loss(logits, lab)       # shifted cross-entropy, HF's ForCausalLMLoss (vcla_causal_lm_loss)
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache if use_cache else None)
