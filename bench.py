@@ -49,6 +49,8 @@ def parse(argv=None):
     ap.add_argument("--steps-b64", type=int, default=5, help="timed steps of the second workload (configs[2], B = 64 per GPU); 0 = skip it")
     ap.add_argument("--steps-c4", type=int, default=2, help="timed steps of the third workload (BASELINE configs[4] per GPU: fp8 weights, 336 px, "
                     "B = 32 = 256 / 8); 0 = skip it")
+    ap.add_argument("--steps-strong", type=int, default=1, help="timed steps of the fourth workload `strong256`: north_star's scaling claim -- a GLOBAL batch of 256 "
+                    "requests (bf16, 224 px) split evenly over the ranks (B = 256 at N = 1 ... B = 32 at N = 8); 0 = skip it")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many requests in total, split evenly over the ranks "
                     "(e.g. 256 = north_star's '>= 6x images/sec 1 -> 8 GPUs at batch 256'); replaces --batch, reports scaling = strong")
     ap.add_argument("--prompt-len", type=int, default=128)
@@ -461,10 +463,28 @@ def plumbing_check(args, rank, world):
     dt, out = timed_workload(step, args.steps, args.warmup, world, lambda: None, barrier, allmax)
     want = torch.arange(gB)[:, None] * 1000 + torch.arange(n_new)[None, :]
     assert torch.equal(out, want), (rank, out, want)
+    # the `strong256` leg of the real run: a GLOBAL batch of 256 split over the ranks (shard sizes 256 // world), gathered the same way
+    strong = None
+    if args.steps_strong > 0 and 256 % world == 0:
+        slo, shi = shard_range(256, rank, world)
+        assert shi - slo == 256 // world
+
+        def sstep():
+            toks = (torch.arange(slo, shi)[:, None] * 1000 + torch.arange(n_new)[None, :]).to(torch.int64)
+            return gather_tokens(toks, n_total=256, n_cols=n_new) if world > 1 else toks
+        sdt, sout = timed_workload(sstep, args.steps_strong, 1, world, lambda: None, barrier, allmax)
+        assert torch.equal(sout, torch.arange(256)[:, None] * 1000 + torch.arange(n_new)[None, :])
+        pdt, _ = timed_workload(sstep, 1, 0, world, lambda: None, barrier, allmax)        # stands in for the first-token generate()
+        strong = {"batch_per_gpu": 256 // world, "global_batch": 256, "steps": args.steps_strong, "scaling": "strong",
+                  "images_per_sec": round(256 * args.steps_strong / sdt, 1), "images_per_sec_prefill": round(256 / pdt, 1)}
     if rank == 0:
-        print(json.dumps({"metric": "plumbing check (no model)", "value": round(gB * n_new * args.steps / dt, 1), "unit": "tokens/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                          "config": {"workload": "token-pattern stand-in", "global_batch": gB, "parallelism": f"dp{world}"}}))
+        out = {"metric": "plumbing check (no model)", "value": round(gB * n_new * args.steps / dt, 1), "unit": "tokens/s",
+               "images_per_sec": round(gB * args.steps / dt, 1), "images_per_sec_prefill": round(gB * args.steps / dt, 1),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+               "config": {"workload": "token-pattern stand-in", "global_batch": gB, "parallelism": f"dp{world}"}}
+        if strong:
+            out["strong256"] = strong
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -513,7 +533,9 @@ def main():
 
     def run_workload(B, steps, warmup):
         """B requests per GPU: every rank builds ONLY its shard of the global batch (request r is seeded by r, so a shard does
-        not depend on the world size), generate() + one all-gather of the ids per step"""
+        not depend on the world size), generate() + one all-gather of the ids per step.  Two throughput definitions per leg:
+        `images_per_sec` = whole requests (vision + prefill + all decode steps), `images_per_sec_prefill` = SURVEY.md 8(d)'s "images through
+        ViT + Resampler + projection + prefill" (one generate(max_new_tokens=1) per batch, timed on every rank, max over ranks)."""
         gB = B * world
         lo, hi = shard_range(gB, rank, world)
         px, ids, mask = make_inputs(model.config, hi - lo, args.prompt_len, first_request=lo)
@@ -530,28 +552,31 @@ def main():
         assert out.shape == (gB, args.new_tokens), out.shape
         res = {"batch_per_gpu": B, "global_batch": gB, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
                "tokens_per_sec": round(gB * args.new_tokens * steps / dt, 2), "images_per_sec": round(gB * steps / dt, 4)}
-        if rank == 0:   # stage split of one step (outside the timed region): vision stack, + splice/prefill/first token, + decode
-            def timed(fn, reps=2):
-                fn()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                sync()
-                return (time.perf_counter() - t0) / reps * 1e3
-            # the vision stack as generate() runs it: on a side stream with persistent buffers (the engine replays its captured graph
-            # there; on the default stream it would issue the ~250 launches eagerly)
-            vis_stream = torch.cuda.Stream(device=dev)
 
-            def vision_once():
-                with torch.cuda.stream(vis_stream):
-                    model.embed_images(px, _persistent=not args.no_graph)
-            t_vis = timed(vision_once, reps=3)
-            t_pre = timed(lambda: model.generate(**dict(kw, max_new_tokens=1)), reps=3)
-            t_step = dt / steps * 1e3
-            res["breakdown_ms"] = {"vision_ms": round(t_vis, 2), "prefill_first_token_ms": round(t_pre - t_vis, 2),
-                                   "decode_ms": round(t_step - t_pre, 2),
-                                   "decode_ms_per_token_step": round((t_step - t_pre) / max(args.new_tokens - 1, 1), 3)}
+        def timed(fn, reps=2):       # barrier + sync on both sides, max over ranks: the same bracket as the main measurement
+            fn()
+            barrier()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync()
+            barrier()
+            return allmax(time.perf_counter() - t0) / reps * 1e3
+        # stage split of one step: vision stack, + splice / prefill / first token, + decode.  The vision stack as generate() runs it: on a side
+        # stream with persistent buffers (the engine replays its captured graph there; on the default stream it would issue ~250 launches eagerly)
+        vis_stream = torch.cuda.Stream(device=dev)
+
+        def vision_once():
+            with torch.cuda.stream(vis_stream):
+                model.embed_images(px, _persistent=not args.no_graph)
+        t_vis = timed(vision_once, reps=3)
+        t_pre = timed(lambda: model.generate(**dict(kw, max_new_tokens=1)), reps=3)
+        t_step = dt / steps * 1e3
+        res["images_per_sec_prefill"] = round(gB / (t_pre * 1e-3), 3)
+        res["breakdown_ms"] = {"vision_ms": round(t_vis, 2), "prefill_first_token_ms": round(t_pre - t_vis, 2),
+                               "decode_ms": round(t_step - t_pre, 2),
+                               "decode_ms_per_token_step": round((t_step - t_pre) / max(args.new_tokens - 1, 1), 3)}
         return res
 
     strong = args.global_batch > 0
@@ -586,6 +611,13 @@ def main():
         model.set_image_size(224)
         c4_res = dict(legs["w8a16"], mode="w8a16", w8a8=legs["w8a8"])
 
+    strong_res = None
+    if args.steps_strong > 0 and args.batch == 1 and not strong and not args.fp8 and args.image_size == 224 and not args.sample and 256 % world == 0:
+        # north_star: ">= 6x images/sec scaling 1 -> 8 GPUs at batch 256": the GLOBAL batch is fixed at 256 and split over the ranks (B = 256 on
+        # one GPU ... B = 32 on each of 8), so the driver's `bench.py --gpus N` series reads that curve off this leg without any flag
+        strong_res = run_workload(256 // world, args.steps_strong, 1)
+        strong_res["scaling"] = "strong"
+
     if rank == 0:
         B = args.batch
         cfgd = {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
@@ -599,7 +631,10 @@ def main():
             "value": main_res["tokens_per_sec"], "unit": "tokens/s",
             # images/sec is the throughput figure of BASELINE configs[2] (B = 64 per GPU) when that workload ran, else the main workload's
             "images_per_sec": (b64_res or main_res)["images_per_sec"],
-            "images_per_sec_workload": f"batch={(b64_res or main_res)['batch_per_gpu']}/GPU",
+            "images_per_sec_prefill": (b64_res or main_res)["images_per_sec_prefill"],
+            "images_per_sec_workload": (f"batch={(b64_res or main_res)['batch_per_gpu']}/GPU; images_per_sec = whole requests (vision + prefill + "
+                                        f"{args.new_tokens} decode steps), images_per_sec_prefill = images through ViT + Resampler + projection + prefill "
+                                        "(SURVEY.md 8d), one first-token generate() per batch"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 weights: W8A16 in the decode steps (dequantised in registers), W8A8 on the fp8 MFMA pipe in the "
@@ -610,6 +645,10 @@ def main():
         }
         if b64_res:
             res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
+        if strong_res:
+            res["strong256"] = dict(strong_res, workload=f"VisualCLA-7B bf16, GLOBAL batch 256 split over {world} GPU(s) = {256 // world} image(s)/GPU, 224 px, T=128, "
+                                                          f"{args.new_tokens} greedy tokens (north_star's strong-scaling workload: compare images_per_sec / "
+                                                          "images_per_sec_prefill of this leg across --gpus 1 / 2 / 4 / 8)")
         if c4_res:
             res["config4"] = dict(c4_res, workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
                                                    "128 greedy tokens (BASELINE configs[4], one GPU's share); headline mode w8a16, the W8A8 prefill mode under `w8a8`")
@@ -631,7 +670,7 @@ def main():
             res["roofline"] = r
             if r:
                 rl.append(r)
-        rl += step_rooflines(b1, b64, cfgd, args.fp8, bool(args.fp8_kv), main_res if B not in (1, 64) else None)
+        rl += step_rooflines(b1, b64, cfgd, args.fp8, bool(args.fp8_kv), main_res if B not in (1, 64) else strong_res)
         res["rooflines"] = rl
         if not args.no_cpu_baseline and world == 1 and args.image_size == 224:   # the CPU baseline is reported by the N=1 run only
             try:

@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define VCLA_ABI_VERSION 3
+#define VCLA_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -190,6 +190,20 @@ typedef struct vcla_gemm_args {
        a_row_ssq, no fp8 weight scale, no bias applied; C / C_frag / c_row_ssq untouched) for a consumer that sums them itself
        (vcla_attn_decode_fused_parts: the qkv projection of a batch decode step).  a_row_ssq may be set (it is not applied). */
     int ds_raw_partials;
+    /* SLAB-MAJOR operands for the LDS-DMA tile kernels (ABI v4).  Measured on MI355X (profiles/r05_l2_intake.txt): a wave instruction
+       that moves 1 KiB CONTIGUOUS global bytes into LDS sustains ~50 B/clk/CU, one that gathers 8 rows x 128 B (or 4 x 256, 2 x 512) of a
+       row-major matrix only ~19 B/clk/CU -- and the K slab (64 elements = 128 B per row) of a tile is exactly such a gather.  In the
+       slab-major layout the matrix is stored K-slab by K-slab, [K/64][rows][64]: element (r, k) at ((k/64) * rows + r) * 64 + k % 64, so the
+       slab of ANY run of 8 rows is one contiguous 1 KiB.  A_slab [K/64][a_slab_rows][64] bf16 (a_slab_rows >= M) replaces A when set;
+       W_slab [K/64][N_pad][64] bf16 replaces W; W_q8_slab [K/64][N_pad][64] e4m3 bytes (16 rows = 1 KiB) replaces W_q8 (w_scale as before).
+       C_slab [N_out/64][c_slab_rows][64] bf16 (N_out % 64 == 0) is an optional SECOND output in the same layout: the next GEMM's A_slab
+       (C may then be NULL).  Ring kernel (11 - 14) and 256x256 kernel (4); visualcla/weights.py:to_slab_major. */
+    const void* A_slab;
+    int64_t a_slab_rows;
+    const void* W_slab;
+    const void* W_q8_slab;
+    void* C_slab;
+    int64_t c_slab_rows;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

@@ -261,6 +261,37 @@ def test_gemm_ring_fp8_weights(lib, M, N, K, epi, f32out):
     _cmp(f"gemm_ring_fp8[{M}x{N}x{K},epi{epi}]", got, ref, atol=3e-4 if f32out else 4e-3, rtol=2e-5 if f32out else 8e-3)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,N,K,epi,fk", [(256, 4096, 4096, 0, 11), (256, 22016, 4096, 3, 11), (200, 12288, 4096, 0, 11), (255, 4096, 11008, 0, 11), (131, 1000, 128, 3, 12),
+                                          (250, 333, 704, 0, 13), (144, 64, 4096, 0, 14), (130, 200, 192, 0, 11)])
+def test_gemm_ring_slab_major_operands(lib, M, N, K, epi, fk, fp8):
+    """slab-major A / W / W_q8 ([K/64][rows][64]: the K slab of 8 rows is one contiguous KiB -- the DMA-friendly layout, vcla_gemm_args.A_slab):
+    bit-identical to the same kernel on the row-major operands (same LDS image, same arithmetic), ragged row counts included"""
+    from visualcla.weights import to_slab_major, from_slab_major, quantize_fp8_rows
+    if epi == 3:
+        N = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    a = bf16r(torch.randn(M, K, generator=g)).to(DEV, torch.bfloat16)
+    wp = _pack(bf16r(torch.randn(N, K, generator=g) * 0.05))
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g)).to(DEV, torch.bfloat16)
+    a_rows = (M + 7) // 8 * 8 + 8                               # a_slab_rows > M: rows beyond M are never read
+    a_pad = torch.zeros(a_rows, K, dtype=torch.bfloat16, device=DEV)
+    a_pad[:M] = a
+    a_sl = to_slab_major(a_pad)
+    assert torch.equal(from_slab_major(a_sl)[:M], a)
+    if fp8:
+        q, sc = quantize_fp8_rows(wp)
+        base = lib.gemm(a, wp, N, residual=res, epilogue=epi, force_kernel=fk, w_q8=q, w_scale=sc)
+        got = lib.gemm(None, wp, N, residual=res, epilogue=epi, force_kernel=fk, w_q8_slab=to_slab_major(q), w_scale=sc, a_slab=a_sl, m=M)
+        mixed = lib.gemm(a, wp, N, residual=res, epilogue=epi, force_kernel=fk, w_q8_slab=to_slab_major(q), w_scale=sc)
+    else:
+        base = lib.gemm(a, wp, N, residual=res, epilogue=epi, force_kernel=fk)
+        got = lib.gemm(None, wp, N, residual=res, epilogue=epi, force_kernel=fk, w_slab=to_slab_major(wp), a_slab=a_sl, m=M)
+        mixed = lib.gemm(None, wp, N, residual=res, epilogue=epi, force_kernel=fk, a_slab=a_sl, m=M)
+    assert torch.equal(got, base) and torch.equal(mixed, base)
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "gemv"])
 def test_gemm_f32_output_and_identity(lib, kernel):
     """A = I (asymmetric W) catches operand/row-column swaps; fp32 output keeps the full accumulator."""
@@ -804,11 +835,12 @@ def test_attention_mfma(lib, B, H, Tq, Tk, D, causal):
     _cmp(f"attn_mfma_vs_generic[Tq{Tq}Tk{Tk}D{D}]", got, gen.float(), atol=1.6e-2)
 
 
-@pytest.mark.parametrize("B,H,T", [(64, 16, 257), (3, 2, 257), (1, 1, 257), (2, 4, 65), (40, 4, 65)])
+@pytest.mark.parametrize("B,H,T", [(64, 16, 257), (3, 2, 257), (1, 1, 257), (2, 4, 65), (40, 4, 65), (32, 16, 577), (2, 3, 577), (1, 1, 577), (9, 16, 577)])
 def test_attention_vit_whole_sequence(lib, B, H, T):
     """force_kernel 3: the whole-sequence ViT self-attention (4 waves x 64 query rows on MFMA, the 257th key and the 257th query row on
     the VALU, the last row merged from per-wave partials) against the fp32 reference, through the strided fused-qkv layout the engine
-    uses; and the automatic dispatch (B * H >= 128) must give the same bits as the forced kernel."""
+    uses; and the automatic dispatch (B * H >= 128) must give the same bits as the forced kernel.  T = 577 (336-px images, round 5): the
+    8-wave form with the whole 148 KB of K / V parked in LDS and the 37 q-tiles taken in two passes (attn_vit_long_kernel)."""
     D = 64
     g = torch.Generator().manual_seed(B * 7 + H + T)
     qkv = bf16r(torch.randn(B, T, 3, H, D, generator=g) * 1.5)
@@ -1224,7 +1256,11 @@ def test_quant_fp8_rows_matches_torch(lib, rows, cols):
     assert torch.equal(q.cpu(), q_ref)                                 # same scale, same round-to-nearest-even
 
 
-FP8_MFMA_SHAPES = [(300, 512, 256, 0), (1000, 1000, 1408, 1), (257, 384, 128, 2), (514, 2048, 1024, 3), (2 * 257, 4096, 1024, 1), (130, 320, 11008, 0)]
+FP8_MFMA_SHAPES = [(300, 512, 256, 0), (1000, 1000, 1408, 1), (257, 384, 128, 2), (514, 2048, 1024, 3), (2 * 257, 4096, 1024, 1), (130, 320, 11008, 0),
+                   # the four GEMMs of a LLaMA-7B layer at the BASELINE widths (a 256-row prefill; o_proj at 1024 rows = 4 row tiles): the kernel is EXACT on the
+                   # operands it is given -- this is where W8A8's kernel error is separated from its format noise (tests/test_gpu_model.py explains why a layer-level
+                   # comparison cannot do it)
+                   (256, 12288, 4096, 0), (256, 22016, 4096, 3), (300, 4096, 11008, 0), (1024, 4096, 4096, 0)]
 
 
 @pytest.mark.parametrize("M,N,K,epi", FP8_MFMA_SHAPES)

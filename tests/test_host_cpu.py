@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vcla_version() == 3
+    assert lib.vcla_version() == 4
 
 
 def test_no_gpu_fails_loudly():
@@ -188,6 +188,11 @@ def test_bench_self_spawns_ranks_and_gathers_once():
     assert len(line) == 1, r.stdout
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 6
+    # the default line carries north_star's strong-scaling workload (global batch 256 split over the ranks) and both images/sec definitions
+    assert res["images_per_sec"] > 0 and res["images_per_sec_prefill"] > 0
+    s256 = res["strong256"]
+    assert s256["global_batch"] == 256 and s256["batch_per_gpu"] == 128 and s256["scaling"] == "strong"
+    assert s256["images_per_sec"] > 0 and s256["images_per_sec_prefill"] > 0
 
 
 def test_synthetic_shards_are_slices_of_the_global_batch():

@@ -28,6 +28,31 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def timeit_graph(fn, reps=20):
+    """like timeit, but the launches of fn() are captured into a hipGraph once and REPLAYED: no Python / ctypes time between kernels (a
+    ~20 us kernel launched from Python measures the interpreter, not the GPU)"""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16)
 
@@ -161,6 +186,89 @@ def main():
             bench_gemm("llama down", Ml, 4096, 11008, fk=fk)
             bench_gemm("square 4096", 4096, 4096, 4096, fk=fk)
             bench_gemm("square 8192", 8192, 8192, 8192, fk=fk)
+    if "ring" in which:
+        print("== 129 - 256-row decode GEMMs (LLaMA-7B layer shapes, rotating 8 weight matrices = no Infinity-Cache reuse): the round-4 dispatch")
+        print("   (k1: 128 x 128 tiles + K slices + reduce launch) vs the ring kernel (k11 auto tile; k12 / k13 / k14 = 256x96 / 128x96 / 64x64), bf16 and fp8 weights")
+        from visualcla.weights import quantize_fp8_rows
+        skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        for M in [int(x) for x in os.environ.get("VCLA_BENCH_MS", "256,192,129").split(",")]:
+            tot = {}
+            for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
+                a = rnd(M, K)
+                ws = [packw(N, K) for _ in range(8)]
+                n_out = N // 2 if epi == 3 else N
+                out = torch.empty(M, n_out, dtype=torch.bfloat16, device=DEV)
+                res = rnd(M, n_out) if tag in ("o", "down") else None
+                q8s = [quantize_fp8_rows(w) for w in ws]
+                from visualcla.weights import to_slab_major
+                a_sl = to_slab_major(a)
+                w_sls = [to_slab_major(w) for w in ws]
+                q_sls = [to_slab_major(q) for q, _ in q8s]
+                fks = [int(x) for x in os.environ.get("VCLA_BENCH_FKS", "1,11,12,13,14").split(",")]
+                for fk, fp8, slab in [(f, p8, sl) for sl in (False, True) for p8 in (False, True) for f in fks]:
+                    if (fk > 12 and epi == 3) or (fk == 1 and (fp8 or slab)):
+                        continue
+                    def run():
+                        for w, (q, sc), wsl, qsl in zip(ws, q8s, w_sls, q_sls):
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, residual=res, force_kernel=fk, splitk_ws=skws if fk == 1 else None,
+                                      w_q8=q if (fp8 and not slab) else None, w_scale=sc if fp8 else None,
+                                      a_slab=a_sl if slab else None, w_slab=wsl if (slab and not fp8) else None, w_q8_slab=qsl if (slab and fp8) else None)
+                    t = timeit_graph(run, reps=10) / len(ws)
+                    gbs = N * K * (1 if fp8 else 2) / t / 1e9
+                    tf = 2.0 * M * N * K / t / 1e12
+                    print(f"ring  M={M:3d} {tag:8s} k{fk:<2d} {'fp8 ' if fp8 else 'bf16'} {'slab-major' if slab else 'row-major '} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {gbs:7.1f} GB/s of W  {tf:7.1f} TF/s")
+                    key = (fk, fp8, slab)
+                    tot[key] = tot.get(key, 0.0) + t
+                del w_sls, q_sls
+                del ws, q8s
+            print(f"ring  M={M:3d} layer sums (qkv + o + gate/up + down): " + "  ".join(f"k{fk}{'/fp8' if f8 else ''}{'/slab' if sl else ''}={v*1e6:.0f}us" for (fk, f8, sl), v in tot.items() if fk in (1, 11)))
+    if "slab256" in which:
+        print("== 256 x 256 direct-to-LDS kernel (k4): row-major operands (8-row x 128-byte DMA pieces) vs slab-major A / W (1 KiB contiguous pieces), hipGraph replay")
+        from visualcla.weights import to_slab_major
+        shapes = [("vit qkv", 64 * 257, 3072, 1024, 0, True), ("vit out", 64 * 257, 1024, 1024, 0, True), ("vit fc1", 64 * 257, 4096, 1024, 1, True),
+                  ("vit fc2", 64 * 257, 1024, 4096, 0, True), ("vit fc1 M=16384", 16384, 4096, 1024, 1, True),
+                  ("llama qkv", 8192, 12288, 4096, 0, False), ("llama o", 8192, 4096, 4096, 0, False), ("llama gate-up", 8192, 22016, 4096, 3, False),
+                  ("llama down", 8192, 4096, 11008, 0, False)]
+        for tag, M, N, K, epi, has_bias in shapes:
+            a = rnd(M, K)
+            nw = 4
+            ws = [packw(N, K) for _ in range(nw)]
+            bias = torch.randn(N, device=DEV) if has_bias else None
+            out = torch.empty(M, N // 2 if epi == 3 else N, dtype=torch.bfloat16, device=DEV)
+            a_sl = to_slab_major(a)
+            w_sls = [to_slab_major(w) for w in ws]
+            ref = None
+            for nm, use_a, use_w in (("row-major A, W", False, False), ("slab A, slab W", True, True), ("slab W only  ", False, True), ("slab A only  ", True, False)):
+                def run():
+                    for w, wsl in zip(ws, w_sls):
+                        _lib.gemm(None if use_a else a, w, N, bias=bias, epilogue=epi, out=out, force_kernel=4, a_slab=a_sl if use_a else None,
+                                  w_slab=wsl if use_w else None, m=M)
+                t = timeit_graph(run, reps=10) / nw
+                tf = 2.0 * M * N * K / t / 1e12
+                if ref is None:
+                    ref = out.clone()
+                same = torch.equal(out, ref)
+                print(f"slab256 {tag:16s} {nm} M={M:6d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:5.1f}% of peak)  {'== row-major result' if same else 'DIFFERS'}")
+            del ws, w_sls
+    if "ringx" in which:
+        print("== ring kernel variants (experiment build: make -C visual-chinese-llama-alpaca_amd/csrc ringx; VCLA_LIB=tools/libvcla_ringx.so), M = 256, bf16 weights")
+        print("   var 0 = DMA burst behind the barrier, 1 = DMA spread over the MFMA groups, 2 = nt weights, 3 = both; ablations (garbage results): 16 / 17 = no reads / MFMAs")
+        print("   (burst / spread), 32 = no weight DMA, 48 = no activation DMA")
+        for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
+            a = rnd(256, K)
+            ws = [packw(N, K) for _ in range(8)]
+            n_out = N // 2 if epi == 3 else N
+            out = torch.empty(256, n_out, dtype=torch.bfloat16, device=DEV)
+            for var in (0, 1, 2, 3, 16, 17, 32, 48):
+                os.environ["VCLA_RING_VAR"] = str(var)
+                for fk in ((11,) if epi == 3 else (11, 12, 13, 14)):
+                    def run():
+                        for w in ws:
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk)
+                    t = timeit(run, reps=10) / len(ws)
+                    print(f"ringx {tag:8s} var={var:2d} k{fk} N={N:6d} K={K:6d}  {t*1e6:8.1f} us")
+            os.environ["VCLA_RING_VAR"] = "0"
+            del ws
     if "vit" in which:
         print("== ViT GEMMs at B=64 through AUTO dispatch (256x256 whole rounds + 64-row tail) vs forced kernels")
         Mv = 64 * 257
@@ -443,6 +551,30 @@ def main():
         bench_attn("vit 336px (B=32)", 32, 16, 577, 577, 64, False, 2)
         bench_attn("resampler (B=64)", 64, 16, 64, 321, 64, False, 2)
         bench_attn("llama prefill (B=64,T=128)", 64, 32, 128, 128, 128, True, 2)
+    if "attn577" in which:
+        print("== ViT self-attention at 336 px (577 tokens, d = 64, fused-qkv strides), B = 32 x 16 heads: tile-by-tile kernel (fk 2) vs whole-sequence kernel (fk 3), hipGraph replay")
+        import ctypes as C
+        for B in (32, 64):
+            H, T, D = 16, 577, 64
+            qkv = rnd(B, T, 3 * H * D)
+            out = torch.empty(B, T, H * D, dtype=torch.bfloat16, device=DEV)
+            for fk in (2, 3):
+                a = _lib.AttnArgs()
+                base = qkv.data_ptr()
+                a.q, a.k, a.v, a.o = base, base + H * D * 2, base + 2 * H * D * 2, out.data_ptr()
+                a.q_bs = a.k_bs = a.v_bs = T * 3 * H * D
+                a.q_hs = a.k_hs = a.v_hs = D
+                a.q_rs = a.k_rs = a.v_rs = 3 * H * D
+                a.o_bs, a.o_hs, a.o_rs = T * H * D, D, H * D
+                a.B, a.H, a.Tq, a.Tk, a.D = B, H, T, T, D
+                a.scale, a.causal, a.force_kernel = 1 / math.sqrt(D), 0, fk
+                L = _lib.load()
+                def run():
+                    for _ in range(4):
+                        _lib.check(L.vcla_attention(C.byref(a), _lib.dtype_code(torch.bfloat16), _lib.stream_ptr()))
+                t = timeit_graph(run, reps=10) / 4
+                fl = 4.0 * B * H * T * T * D
+                print(f"attn577 B={B} fk={fk}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s ({fl/t/1e12/25:.1f}% of the bf16 MFMA peak)")
     if "attn" in which:
         print("== attention")
         for fk in (1, 2):

@@ -37,11 +37,12 @@ struct Args {
     long long w_kb_per_wg;      // KiB per workgroup (0: no stream)
     unsigned long long* a_kb;   // [grid] KiB the readers of a workgroup fetched
     unsigned int* sink;
+    long long ld;               // PAT = 1: the panel is a [rows][ld bytes] matrix read as 8-row x 128-byte pieces (the tile kernels' DMA shape)
 };
 
 // NA reader waves (register loads, L in flight per lane, two batches alternating so that L stay in flight while L are consumed),
 // NW streamer waves (nt loads, 3 stages x 4 KiB per wave in flight: the gemv1p / dstream ring).
-template <int NA, int L, int NW, bool DMA>
+template <int NA, int L, int NW, bool DMA, int PAT = 0>
 __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     __shared__ int stream_left;
@@ -52,7 +53,18 @@ __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
     if (wave < NA) {
         // chunk c of the panel = L KiB; wave w takes chunks w, w + NA, ...
         const long long chunks = a.panel_kb / L;
-        const char* base = (const char*)a.panel + lane * 16;
+        const char* base = (const char*)a.panel + (PAT ? 0 : lane * 16);
+        // PAT = 1: piece p = (row block p % rbl, K slab p / rbl): lane -> row (lane >> 3) of the block, 16-byte chunk (lane & 7) of the slab's 128 bytes
+        // PAT = 2: contiguous 1 KiB, lanes XOR-permuted inside each 128-byte row (the source-side bank swizzle of a slab-major operand);
+        // PAT = 3 / 4: 2 rows x 512 B / 4 rows x 256 B per instruction (K slabs of 256 / 128 of a row-major matrix)
+        auto off = [&](long long p) -> long long {
+            if (PAT == 0) return p * 1024;
+            if (PAT == 2) return p * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 4) & 7)) * 16) - lane * 0;
+            const int rows_per = PAT == 1 ? 8 : (PAT == 3 ? 2 : 4), seg = 1024 / rows_per, lpr = 64 / rows_per;   // bytes and lanes per row segment
+            const long long rbl = (a.panel_kb * 1024 / a.ld) / rows_per;
+            const long long rb = p % rbl, slab = p / rbl;
+            return (rb * rows_per + lane / lpr) * a.ld + slab * seg + (lane % lpr) * 16;
+        };
         unsigned long long got = 0;
         long long c = wave;
         int pass = 0;
@@ -61,16 +73,16 @@ __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
         if constexpr (!DMA) {
             u32x4_t b0[L], b1[L];
 #pragma unroll
-            for (int j = 0; j < L; ++j) b0[j] = *(const u32x4_t*)(base + (c * L + j) * 1024);
+            for (int j = 0; j < L; ++j) b0[j] = *(const u32x4_t*)(base + off(c * L + j));
             next();
             while (more()) {
 #pragma unroll
-                for (int j = 0; j < L; ++j) b1[j] = *(const u32x4_t*)(base + (c * L + j) * 1024);
+                for (int j = 0; j < L; ++j) b1[j] = *(const u32x4_t*)(base + off(c * L + j));
                 next();
 #pragma unroll
                 for (int j = 0; j < L; ++j) acc ^= b0[j];
 #pragma unroll
-                for (int j = 0; j < L; ++j) b0[j] = *(const u32x4_t*)(base + (c * L + j) * 1024);
+                for (int j = 0; j < L; ++j) b0[j] = *(const u32x4_t*)(base + off(c * L + j));
                 next();
 #pragma unroll
                 for (int j = 0; j < L; ++j) acc ^= b1[j];
@@ -83,18 +95,18 @@ __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
             const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)lds + wave * (2 * L * 1024);
             const unsigned char* mine = lds + wave * (2 * L * 1024);
 #pragma unroll
-            for (int j = 0; j < L; ++j) dma16(base + (c * L + j) * 1024, lds_u + j * 1024);
+            for (int j = 0; j < L; ++j) dma16(base + off(c * L + j), lds_u + j * 1024);
             next();
             while (more()) {
 #pragma unroll
-                for (int j = 0; j < L; ++j) dma16(base + (c * L + j) * 1024, lds_u + (L + j) * 1024);
+                for (int j = 0; j < L; ++j) dma16(base + off(c * L + j), lds_u + (L + j) * 1024);
                 next();
                 vmcnt<L>();
 #pragma unroll
                 for (int j = 0; j < L; ++j) acc ^= *(const u32x4_t*)(mine + j * 1024 + lane * 16);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < L; ++j) dma16(base + (c * L + j) * 1024, lds_u + j * 1024);
+                for (int j = 0; j < L; ++j) dma16(base + off(c * L + j), lds_u + j * 1024);
                 next();
                 vmcnt<L>();
 #pragma unroll
@@ -136,11 +148,11 @@ __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
 
 static double g_clk_ghz = 2.4;
 
-template <int NA, int L, int NW, bool DMA>
+template <int NA, int L, int NW, bool DMA, int PAT = 0>
 static void run(const char* tag, Args a, int grid, FILE* out) {
     const size_t lds_bytes = DMA ? (size_t)NA * 2 * L * 1024 : 0;
     if (lds_bytes > 160 * 1024) return;
-    auto kern = intake_kernel<NA, L, NW, DMA>;
+    auto kern = intake_kernel<NA, L, NW, DMA, PAT>;
     if (lds_bytes > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if constexpr (NA > 0) a.panel_kb = a.panel_kb / (NA * L) * (NA * L);
     hipEvent_t e0, e1;
@@ -168,7 +180,7 @@ static void run(const char* tag, Args a, int grid, FILE* out) {
     const double a_bytes_cu = (double)a_kb_tot * 1024 / grid, w_bytes_cu = (double)a.w_kb_per_wg * 1024;
     const double a_gbs = a_bytes_cu / sec / 1e9, w_gbs = w_bytes_cu / sec / 1e9;
     fprintf(out, "%-34s NA=%d L=%d NW=%d %s panel=%5lld KB  t=%8.1f us  A: %6.1f GB/s/CU = %5.1f B/clk/CU (chip %5.2f TB/s)", tag, NA, L, NW,
-            DMA ? "lds-dma" : "vgpr   ", a.panel_kb, sec * 1e6, a_gbs, a_gbs / g_clk_ghz, a_gbs * grid / 1e3);
+            DMA ? (PAT == 1 ? "lds-dma/8x128" : PAT == 2 ? "lds-dma/1K-swz" : PAT == 3 ? "lds-dma/2x512" : PAT == 4 ? "lds-dma/4x256" : "lds-dma") : (PAT ? "vgpr/rows" : "vgpr   "), a.panel_kb, sec * 1e6, a_gbs, a_gbs / g_clk_ghz, a_gbs * grid / 1e3);
     if (NW) fprintf(out, "   W: %6.1f GB/s/CU = %5.1f B/clk/CU (chip %5.2f TB/s)", w_gbs, w_gbs / g_clk_ghz, w_gbs * grid / 1e3);
     fprintf(out, "\n");
     fflush(out);
@@ -196,6 +208,8 @@ int main(int argc, char** argv) {
     const int grid = cus;
     Args a{};
     a.panel = panel; a.wbuf = wbuf; a.a_kb = a_kb; a.sink = sink;
+    const bool full = argc > 1 && argv[1][0] == 'f';
+    if (full) {
     const long long panels_kb[] = {512, 1408, 2048, 5632};
     fprintf(out, "\n## 1. panel alone (every CU reads the same L2-resident panel, %d workgroups)\n", grid);
     for (long long pk : panels_kb) {
@@ -224,5 +238,24 @@ int main(int argc, char** argv) {
     run<8, 4, 0, false>("alone, 2 WG/CU", a, 2 * grid, out);
     a.w_kb_per_wg = 2816;
     run<4, 4, 4, false>("beside stream, 2 WG/CU", a, 2 * grid, out);
+    }
+    // ---- 5. the tile kernels' DMA shape: 8 rows x 128 B per wave instruction out of a [256][ld] matrix (ld = 8 KiB: K = 4096; 22016 B: K = 11008),
+    //         against 1 KiB contiguous per instruction (sections 1 - 4).  Same bytes, same L2 residency.
+    fprintf(out, "\n## 5. 8-row x 128-byte pieces of a [256][ld] row-major matrix vs contiguous 1 KiB pieces (alone)\n");
+    for (long long ld : {8192LL, 22016LL}) {
+        a.ld = ld; a.panel_kb = 256 * ld / 1024; a.w_kb_per_wg = 0; a.passes = (int)(16384 / a.panel_kb) + 2;
+        fprintf(out, "# ld = %lld bytes, panel %lld KB\n", ld, a.panel_kb);
+        run<8, 4, 0, false, 0>("contiguous", a, grid, out); run<8, 4, 0, true, 0>("contiguous", a, grid, out);
+        run<8, 4, 0, false, 1>("row pieces", a, grid, out); run<8, 4, 0, true, 1>("row pieces", a, grid, out);
+        run<8, 8, 0, true, 1>("row pieces", a, grid, out);
+        run<8, 8, 0, true, 0>("contiguous", a, grid, out);
+        run<8, 4, 0, true, 2>("1 KiB, lanes swizzled in rows", a, grid, out);
+        run<8, 4, 0, true, 3>("2 rows x 512 B", a, grid, out);
+        run<8, 4, 0, true, 4>("4 rows x 256 B", a, grid, out);
+        a.w_kb_per_wg = 2816;
+        run<8, 4, 4, true, 0>("contiguous beside stream", a, grid, out);
+        run<8, 4, 4, true, 1>("row pieces beside stream", a, grid, out);
+        a.w_kb_per_wg = 0;
+    }
     return 0;
 }

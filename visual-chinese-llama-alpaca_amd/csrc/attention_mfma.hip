@@ -946,16 +946,290 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FA_STAMP(11);
 }
 
+// =================================================================== whole-sequence ViT attention for 336-px images: 577 = 9 x 64 + 1 tokens, d = 64
+// (BASELINE configs[4]; hf clip/modeling_clip.py:259-335).  K / V of one (image, head) are 148 KB: they fit ONE workgroup's LDS (160 KiB per
+// CU) but not two, so the 257-token kernel's geometry (4 waves x 64 query rows, two workgroups per CU) does not transfer.  Here ONE 8-wave
+// workgroup owns the (image, head): the whole K / V sequence is parked in LDS once (all 9 key tiles requested up front with LDS-DMA in
+// consumption order, hand-counted vmcnt, one bare barrier per tile as in attn_vit_dma_kernel) and the 577 query rows are 37 sixteen-row
+// MFMA q-tiles -- 36 real ones plus one whose every row is the LAST row (row 0 of it is stored) -- taken in two passes over the resident
+// image: pass 1 = 8 waves x 4 q-tiles (rows 0 .. 511) while the tiles land, pass 2 = waves 0 .. 4 x 1 q-tile (rows 512 .. 575 and the last
+// row), no memory wait left in it.  The 577th KEY is folded in on the VALU from LDS in both passes.  The tile-by-tile kernel this replaces
+// staged every key tile three times per head (three 9-wave workgroups of 192 rows) behind two barriers each: 123.7 us per layer at B = 32
+// (14 % of the MFMA peak, profiles/r04_bench_fp8_336px_b32_by_grid.txt).
+template <int QT>
+__device__ __forceinline__ void vit_key_tile(const unsigned char* ks, __attribute__((address_space(3))) unsigned char* vbase, const bf16x8_t (&qf)[QT][2],
+                                             f32x4_t (&o)[QT][4], float (&m_run)[QT], float (&l_run)[QT], float sl2, int ql, int g) {
+    constexpr int D = 64, KST = 2, DT = 4;
+    f32x4_t sacc[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sacc[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KST; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + fa_k_off<D>(t * 16 + ql, s * 4 + g));
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[qt][t], 0, 0, 0);
+        }
+    bf16x8_t pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
+        mx *= sl2;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][t][r], sl2, -m_new));
+                pv[t * 4 + r] = p;
+                ps += p;
+            }
+        l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 u;
+            u.x = pack_bf2(pv[(2 * s) * 4 + 0], pv[(2 * s) * 4 + 1]);
+            u.y = pack_bf2(pv[(2 * s) * 4 + 2], pv[(2 * s) * 4 + 3]);
+            u.z = pack_bf2(pv[(2 * s + 1) * 4 + 0], pv[(2 * s + 1) * 4 + 1]);
+            u.w = pack_bf2(pv[(2 * s + 1) * 4 + 2], pv[(2 * s + 1) * 4 + 3]);
+            pf[qt][s] = __builtin_bit_cast(bf16x8_t, u);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kr = g * 4 + (ql >> 2), dc = dt * 16 + (ql & 3) * 4;
+            const fa_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s) * 16 + kr, dc)));
+            const fa_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_v4_t)(vbase + fa_v_off<D>((2 * s + 1) * 16 + kr, dc)));
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s], o[qt][dt], 0, 0, 0);
+        }
+}
+
+// the last key (one more than a whole number of tiles) on the VALU, from LDS row `key` of the K / V images
+template <int QT>
+__device__ __forceinline__ void vit_last_key(const unsigned char* ks_all, const unsigned char* vs_all, int key, const bf16x8_t (&qf)[QT][2], f32x4_t (&o)[QT][4],
+                                             float (&m_run)[QT], float (&l_run)[QT], float sl2, int g) {
+    constexpr int D = 64, KST = 2, DT = 4;
+    bf16x8_t kx[KST];
+#pragma unroll
+    for (int s = 0; s < KST; ++s) kx[s] = *reinterpret_cast<const bf16x8_t*>(ks_all + fa_k_off<D>(key, s * 4 + g));
+    uint2 vx[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vx[dt] = *reinterpret_cast<const uint2*>(vs_all + fa_v_off<D>(key, dt * 16 + g * 4));
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float d_ = 0.f;
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 0, 1), __builtin_shufflevector(kx[s], kx[s], 0, 1), d_, false);
+            d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 2, 3), __builtin_shufflevector(kx[s], kx[s], 2, 3), d_, false);
+            d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 4, 5), __builtin_shufflevector(kx[s], kx[s], 4, 5), d_, false);
+            d_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(qf[qt][s], qf[qt][s], 6, 7), __builtin_shufflevector(kx[s], kx[s], 6, 7), d_, false);
+        }
+        d_ += __shfl_xor(d_, 16, 64);
+        d_ += __shfl_xor(d_, 32, 64);
+        const float sx = d_ * sl2;
+        const float m_new = fmaxf(m_run[qt], sx);
+        const float alpha = exp2f(m_run[qt] - m_new), px = __builtin_amdgcn_exp2f(sx - m_new);
+        m_run[qt] = m_new;
+        l_run[qt] = l_run[qt] * alpha + (g == 0 ? px : 0.f);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[qt][dt][0] = __builtin_fmaf(px, __uint_as_float(vx[dt].x << 16), o[qt][dt][0] * alpha);
+            o[qt][dt][1] = __builtin_fmaf(px, __uint_as_float(vx[dt].x & 0xffff0000u), o[qt][dt][1] * alpha);
+            o[qt][dt][2] = __builtin_fmaf(px, __uint_as_float(vx[dt].y << 16), o[qt][dt][2] * alpha);
+            o[qt][dt][3] = __builtin_fmaf(px, __uint_as_float(vx[dt].y & 0xffff0000u), o[qt][dt][3] * alpha);
+        }
+    }
+}
+
+template <int NT>      // key tiles of 64; the sequence is NT * 64 + 1 tokens (NT = 9: 577)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_long_kernel(vcla_attn_args a) {
+    constexpr int KST = 2, DT = 4, QT = 4, NW = 8, NK = NT * 64 + 1;
+    constexpr int ROWS = NT * 64 + 8;                                   // image rows incl. the padded piece of the last key
+    constexpr int IMG = ROWS * 128;                                     // one operand image
+    constexpr int TILE = 64 * 128;
+    static_assert(NT * 64 >= NW * 64 && 2 * IMG <= 160 * 1024, "geometry");
+    static_assert(2 * (NT - 1) + 1 + 8 <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];    // [K image][V image]
+    unsigned char* ks_all = lds_all;
+    unsigned char* vs_all = lds_all + IMG;
+    typedef __attribute__((address_space(3))) void* lds_p;
+    const unsigned lds_u = (unsigned)(uintptr_t)(lds_p)lds_all;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const bf16_t* qb = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* kb = (const bf16_t*)a.k + b * a.k_bs + h * a.k_hs;
+    const bf16_t* vb = (const bf16_t*)a.v + b * a.v_bs + h * a.v_hs;
+    bf16_t* ob = (bf16_t*)a.o + b * a.o_bs + h * a.o_hs;
+    const int ql = lane & 15, g = lane >> 4;
+    const int qw = wave * 64;                                            // pass 1: this wave's 64 query rows
+    const float sl2 = a.scale * 1.44269504088896340736f;
+
+    // ---- DMA lane maps (as attn_vit_dma_kernel): lane = (row within the 8-row piece, 16-byte slot p); the chunk that belongs in slot p of `row`
+    const int prow = lane >> 3, pslot = lane & 7;
+    auto k_chunk = [&](int row) { return pslot ^ ((row >> 1) & 7); };
+    auto v_chunk = [&](int row) { return ((((pslot >> 1) ^ (row >> 1)) & 3) << 1) + (pslot & 1); };
+    // pass-1 Q fragments: register loads hipcc does not see, completed by the counted wait in front of key tile 0 (form (ii) of the guide)
+    u32x4_t qv[QT][KST];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2) {
+            const bf16_t* qp = qb + (int64_t)(qw + qt * 16 + ql) * a.q_rs + s2 * 32 + g * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[qt][s2]) : "v"(qp) : "memory");
+        }
+    // key tiles in consumption order: 16 pieces per tile (8 K + 8 V), one K and one V piece per wave
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int row = t * 64 + wave * 8 + prow;
+        fa_dma16(kb + (int64_t)row * a.k_rs + k_chunk(row) * 8, __builtin_amdgcn_readfirstlane(lds_u + (t * 64 + wave * 8) * 128));
+        fa_dma16(vb + (int64_t)row * a.v_rs + v_chunk(row) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (t * 64 + wave * 8) * 128));
+    }
+    // the last key's K / V rows: one padded 8-row piece each (rows clamped to the last one); EVERY wave issues one (even waves K, odd waves V:
+    // identical bytes to the same place) so that the VMEM queue has the same length in every wave: [Q: 8][tile 0: 2] ... [tile NT-1: 2][last: 1]
+    if ((wave & 1) == 0) fa_dma16(kb + (int64_t)(NK - 1) * a.k_rs + k_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + (NK - 1) * 128));
+    else fa_dma16(vb + (int64_t)(NK - 1) * a.v_rs + v_chunk(NK - 1 + prow) * 8, __builtin_amdgcn_readfirstlane(lds_u + IMG + (NK - 1) * 128));
+
+    bf16x8_t qf[QT][KST];
+    f32x4_t o[QT][DT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    // vmcnt retires in order: "at most 2 (NT - 1) + 1 outstanding" = Q and this wave's pieces of tile 0 have landed; every wave says so at the barrier
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(qv[0][0]), "+v"(qv[0][1]), "+v"(qv[1][0]), "+v"(qv[1][1]), "+v"(qv[2][0]), "+v"(qv[2][1]), "+v"(qv[3][0]), "+v"(qv[3][1])
+                 : "n"(2 * (NT - 1) + 1) : "memory");
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2) qf[qt][s2] = __builtin_bit_cast(bf16x8_t, qv[qt][s2]);
+    // ---- pass 1: rows wave * 64 .. + 63 over the key tiles as they land
+#pragma unroll 1
+    for (int tile = 0; tile < NT; ++tile) {
+        // tile t is ready once at most 2 (NT - 1 - t) + 1 younger instructions are outstanding; the wait for tile 0 was taken above
+        switch (NT - 1 - tile) {
+            case 0: fa_vmcnt<1>(); break;
+            case 1: fa_vmcnt<3>(); break;
+            case 2: fa_vmcnt<5>(); break;
+            case 3: fa_vmcnt<7>(); break;
+            case 4: fa_vmcnt<9>(); break;
+            case 5: fa_vmcnt<11>(); break;
+            case 6: fa_vmcnt<13>(); break;
+            case 7: fa_vmcnt<15>(); break;
+            default: fa_vmcnt<2 * (NT - 1) + 1>(); break;
+        }
+        fa_lds_barrier();
+        vit_key_tile<QT>(ks_all + tile * TILE, (__attribute__((address_space(3))) unsigned char*)lds_all + IMG + tile * TILE, qf, o, m_run, l_run, sl2, ql, g);
+    }
+    fa_vmcnt<0>();
+    fa_lds_barrier();                                                    // the last key's rows have landed for everyone
+    vit_last_key<QT>(ks_all, vs_all, NK - 1, qf, o, m_run, l_run, sl2, g);
+    // normalise O and pack it to bf16 (32 registers across pass 2); it leaves through LDS as whole rows once K / V are no longer needed
+    uint2 opk[QT][DT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            opk[qt][dt] = make_uint2(pack_bf2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+    }
+    // ---- pass 2: the remaining (NT - NW) * 64 rows as 16-row q-tiles on waves 0 .., then ONE q-tile whose every row is the last row.
+    // K / V are resident: no wait, no barrier.  (NT = 9: waves 0 - 3 take rows 512 .. 575, wave 4 the last row; waves 5 - 7 are done.)
+    constexpr int Q2 = (NT - NW) * 4;                                     // 16-row q-tiles left after pass 1
+    static_assert(Q2 + 1 <= NW, "pass 2 is one q-tile per wave");
+    if (wave <= Q2) {
+        const int row2 = wave < Q2 ? NW * 64 + wave * 16 + ql : NK - 1;
+        bf16x8_t qf2[1][KST];
+#pragma unroll
+        for (int s2 = 0; s2 < KST; ++s2) qf2[0][s2] = *reinterpret_cast<const bf16x8_t*>(qb + (int64_t)row2 * a.q_rs + s2 * 32 + g * 8);
+        f32x4_t o2[1][DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o2[0][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float m2[1] = {-INFINITY}, l2[1] = {0.f};
+#pragma unroll 1
+        for (int tile = 0; tile < NT; ++tile)
+            vit_key_tile<1>(ks_all + tile * TILE, (__attribute__((address_space(3))) unsigned char*)lds_all + IMG + tile * TILE, qf2, o2, m2, l2, sl2, ql, g);
+        vit_last_key<1>(ks_all, vs_all, NK - 1, qf2, o2, m2, l2, sl2, g);
+        float l = l2[0];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (wave < Q2 || ql == 0) {                                      // the last-row tile: lanes (0, g) hold row 0 = the row itself
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<uint2*>(ob + (int64_t)row2 * a.o_rs + dt * 16 + g * 4) =
+                    make_uint2(pack_bf2(o2[0][dt][0] * inv, o2[0][dt][1] * inv), pack_bf2(o2[0][dt][2] * inv, o2[0][dt][3] * inv));
+        }
+    }
+    __syncthreads();                      // every wave is done with K / V: the images are free
+    // ---- pass-1 O leaves as WHOLE ROWS through the wave's own 8 KiB of the K image (as attn_vit_dma_kernel): 8 dwordx4 stores per lane
+    {
+        unsigned char* os = ks_all + wave * TILE;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = qt * 16 + ql, c = dt * 2 + (g >> 1);
+                *reinterpret_cast<uint2*>(os + row * 128 + ((c ^ (row & 7)) << 4) + (g & 1) * 8) = opk[qt][dt];
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + prow;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(os + row * 128 + ((pslot ^ (row & 7)) << 4));
+            *reinterpret_cast<u32x4_t*>(ob + (int64_t)(qw + row) * a.o_rs + pslot * 8) = v;
+        }
+    }
+}
+
 static bool attn_vit_shape(const vcla_attn_args* a) {
     if (a->causal || a->key_mask || a->tk_dev || a->D != 64 || a->Tq != a->Tk) return false;
+    if (a->Tq == 577) return vcla_aligned(a->o, 16) && a->o_bs % 8 == 0 && a->o_hs % 8 == 0 && a->o_rs % 8 == 0;     // 336 px: attn_vit_long_kernel (16-byte O pieces)
     return a->Tq == 65 || a->Tq == 257;      // NWM = 1, 4 (a 2-wave instance spills its 72 staging registers; 129 tokens is no ViT geometry here)
 }
 
 int vcla_attention_vit(const vcla_attn_args* a, void* stream) {
     VCLA_REQUIRE(attn_vit_shape(a) && vcla_attention_mfma_supported(a) && vcla_aligned(a->o, 2), VCLA_ERR_BAD_ARG,
-                 "attention: the whole-sequence ViT kernel needs an unmasked bidirectional d = 64 self-attention over 65 / 257 tokens");
+                 "attention: the whole-sequence ViT kernel needs an unmasked bidirectional d = 64 self-attention over 65 / 257 / 577 tokens");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(1, a->H, a->B);
+    if (a->Tq == 577) {      // 336 px (BASELINE configs[4]): one 8-wave workgroup per (image, head), the whole 148 KB of K / V in LDS
+        auto kern = attn_vit_long_kernel<9>;
+        const size_t lds = (size_t)2 * (9 * 64 + 8) * 128;
+        static bool attr_long[VCLA_MAX_DEVICES] = {};
+        const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_long);
+        if (rc_) return rc_;
+        kern<<<grid, 512, lds, s>>>(*a);
+        VCLA_CHECK_LAUNCH("attn_vit_long_kernel");
+        return VCLA_OK;
+    }
     static const int abl_env = getenv("VCLA_ATTN_VIT_ABL") ? atoi(getenv("VCLA_ATTN_VIT_ABL")) : 0;
 #define VIT_GO(NWM_)                                                                                                 \
     {                                                                                                                \

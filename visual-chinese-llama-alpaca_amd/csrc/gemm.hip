@@ -1234,7 +1234,10 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
     VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
-    VCLA_REQUIRE((a->A || a->A_frag || a->A_q8) && a->W && (a->C || a->C_frag), VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE((a->A || a->A_frag || a->A_q8 || a->A_slab) && a->W && (a->C || a->C_frag || a->C_slab), VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE(!(a->A_slab || a->W_slab || a->W_q8_slab || a->C_slab) || (a->force_kernel >= 11 && a->force_kernel <= 14) || a->force_kernel == 4, VCLA_ERR_BAD_ARG,
+                 "gemm: slab-major operands belong to the ring kernel (force_kernel 11 - 14) and the 256 x 256 kernel (4)");
+    VCLA_REQUIRE(!a->A_slab || (vcla_aligned(a->A_slab, 16) && a->a_slab_rows >= a->M), VCLA_ERR_BAD_ARG, "gemm: A_slab must be 16-byte aligned with a_slab_rows >= M");
     VCLA_REQUIRE(a->epilogue >= VCLA_EPI_NONE && a->epilogue <= VCLA_EPI_SWIGLU, VCLA_ERR_BAD_ARG, "gemm: bad epilogue %d",
                  a->epilogue);
     VCLA_REQUIRE(a->epilogue != VCLA_EPI_SWIGLU || a->N % 32 == 0, VCLA_ERR_BAD_SHAPE,
@@ -1304,10 +1307,12 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(a->C && !a->C_frag && !a->A_frag && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
                      "gemm: the fp8 MFMA kernel writes a row-major C and takes no fused norms");
     } else if (kernel >= 11) {
-        VCLA_REQUIRE(dtype == VCLA_BF16 && a->A && a->C && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && !a->C_frag &&
+        VCLA_REQUIRE(dtype == VCLA_BF16 && (a->A || a->A_slab) && a->C && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && !a->C_frag &&
                          !a->A_frag && !a->A_q8 && !a->a_scale && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->c_frag_gamma, VCLA_ERR_BAD_ARG,
                      "gemm: the ring kernel takes a row-major bf16 A, epilogue NONE (bf16 / fp32 C) or SWIGLU (bf16 C), no fused norms");
-        VCLA_REQUIRE(!a->W_q8 || (a->w_scale && vcla_aligned(a->W_q8, 16)), VCLA_ERR_BAD_ARG, "gemm: the ring kernel's fp8 weights need W_q8 (16-byte aligned) + w_scale");
+        VCLA_REQUIRE(!(a->W_q8 || a->W_q8_slab) || (a->w_scale && vcla_aligned(a->W_q8, 16) && vcla_aligned(a->W_q8_slab, 16)), VCLA_ERR_BAD_ARG,
+                     "gemm: the ring kernel's fp8 weights need W_q8 or W_q8_slab (16-byte aligned) + w_scale");
+        VCLA_REQUIRE(!a->W_slab || vcla_aligned(a->W_slab, 16), VCLA_ERR_BAD_ARG, "gemm: W_slab must be 16-byte aligned");
     } else if (kernel == 9) {
         VCLA_REQUIRE(dtype == VCLA_BF16 && a->A_frag && vcla_aligned(a->A_frag, 16) && a->M <= 64 && (a->W_frag || a->W_q8_frag), VCLA_ERR_BAD_ARG,
                      "gemm: the streaming kernel needs bf16, A_frag, M <= 64 (got %d) and W_frag or W_q8_frag", a->M);
@@ -1326,8 +1331,10 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
                                            (!a->c_row_ssq || a->N % 16 == 0) && a->K / (a->W_q8_frag ? 64 : 32) >= a->ds_splitk),
                      VCLA_ERR_BAD_ARG, "gemm: ds_splitk needs epilogue NONE, N %% 4 == 0, 4-element aligned rows and a workspace of ds_splitk * M * N * 4 bytes");
     } else {
-        VCLA_REQUIRE(a->A && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->A_q8 && !a->a_scale, VCLA_ERR_BAD_ARG,
+        VCLA_REQUIRE((a->A || (kernel == 4 && a->A_slab)) && a->C && !a->C_frag && !a->c_frag_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->A_q8 && !a->a_scale, VCLA_ERR_BAD_ARG,
                      "gemm: A_frag / C_frag / deferred-norm fields belong to the streaming kernel (9), A_q8 / a_scale to the fp8 MFMA kernel (10)");
+        VCLA_REQUIRE(!(kernel == 4 && (a->A_slab || a->W_slab)) || (a->K >= 3 * GM_BK && !a->W_q8_slab && (!a->W_slab || vcla_aligned(a->W_slab, 16))), VCLA_ERR_BAD_ARG,
+                     "gemm: the 256 x 256 kernel reads slab-major bf16 operands in its direct-to-LDS form only (K >= 192)");
     }
     VCLA_REQUIRE(!((kernel == 1 || kernel == 4 || kernel == 5 || kernel == 7 || kernel == 8 || kernel >= 11) && dtype != VCLA_BF16), VCLA_ERR_BAD_DTYPE, "gemm: MFMA kernels need bf16 activations");
     VCLA_REQUIRE(!(kernel == 3 && dtype != VCLA_F32), VCLA_ERR_BAD_DTYPE, "gemm: fp32 tile kernel needs fp32 activations");
@@ -1336,9 +1343,9 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(!a->norm_gamma || vcla_aligned(a->norm_gamma, 16), VCLA_ERR_BAD_ARG, "gemm: norm_gamma must be 16-byte aligned");
     VCLA_REQUIRE(!((kernel == 7 || kernel == 8) && a->M > 128), VCLA_ERR_BAD_SHAPE, "gemm: skinny / panel kernels need M <= 128 (got %d)", a->M);
     VCLA_REQUIRE(!a->W_frag || (vcla_aligned(a->W_frag, 16) && a->K % 32 == 0), VCLA_ERR_BAD_ARG, "gemm: W_frag must be 16-byte aligned");
-    VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
+    VCLA_REQUIRE((!a->W_q8 && !a->W_q8_frag && !a->W_q8_slab) || (a->w_scale && dtype == VCLA_BF16), VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights need w_scale and bf16 activations");
-    VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
+    VCLA_REQUIRE(!a->w_scale || a->W_q8 || a->W_q8_frag || a->W_q8_slab, VCLA_ERR_BAD_ARG, "gemm: w_scale without fp8 weights");
     VCLA_REQUIRE(!(a->W_q8 || a->W_q8_frag) || kernel == 2 || kernel == 8 || kernel == 9 || kernel == 10 || kernel >= 11, VCLA_ERR_BAD_ARG,
                  "gemm: fp8 weights are implemented for the M = 1 GEMV (needs W_q8), the M <= 128 panel kernel (needs W_q8_frag) and the ring kernel (W_q8)");
     VCLA_REQUIRE(!(kernel == 2 && a->w_scale) || (a->W_q8 && gemv1_applicable(a, dtype)), VCLA_ERR_BAD_ARG,

@@ -112,24 +112,44 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
     set_src(m0, n0);
     if constexpr (PF) {
         const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)lds2;
+        // Operand addressing in BYTES: row-major (rows lda / K elements apart, K slabs 128 B apart) or SLAB-major (vcla_gemm_args.A_slab / W_slab,
+        // [K/64][rows][64]: rows 128 B apart, slabs rows * 128 B apart).  The LDS image is the same either way; with slab-major operands the 8 rows
+        // of a piece are ONE contiguous KiB, which the DMA path moves ~2.5x faster than the 8-row gather (profiles/r05_l2_intake.txt).
+        const char* Ab = (const char*)(a.A_slab ? a.A_slab : a.A);
+        const char* Wb = (const char*)(a.W_slab ? a.W_slab : a.W);
+        const int64_t a_rs = a.A_slab ? 128 : a.lda * 2, a_ss = a.A_slab ? a.a_slab_rows * 128 : 128;
+        const int64_t w_rs = a.W_slab ? 128 : (int64_t)a.K * 2, w_ss = a.W_slab ? (int64_t)n_pad * 128 : 128;
+        const char* asb[4];
+        const char* wsb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            const int row = piece * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (involution shared with lds_off)
+            int am = m0 + row, wr = n0 + row;
+            if (am >= a.M) am = a.M - 1;
+            if (wr >= n_pad) wr = n_pad - 1;
+            asb[i] = Ab + (int64_t)am * a_rs + chunk * 16;
+            wsb[i] = Wb + (int64_t)wr * w_rs + chunk * 16;
+        }
         // XR: the piece that carries row 256 (rows 256 .. 263 of the tile; 257.. are the next tile's first rows, clamped into the matrix)
-        const bf16_t* xsrc = nullptr;
+        const char* xsrc = nullptr;
         if constexpr (XR) {
             const int row = 256 + (lane >> 3);
             int am = m0 + row;
             if (am >= a.M) am = a.M - 1;
-            xsrc = Ag + (int64_t)am * a.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+            xsrc = Ab + (int64_t)am * a_rs + ((lane & 7) ^ ((row >> 1) & 7)) * 16;
         }
         auto issue_pf = [&](int kt, int buf) {
             const unsigned ab = lds_u + buf * STAGE, wb = ab + A_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned piece = __builtin_amdgcn_readfirstlane((wave * 4 + i) * 1024);
-                g2_dma16(asrc[i] + (int64_t)kt * GM_BK, ab + piece);
-                g2_dma16(wsrc[i] + (int64_t)kt * GM_BK, wb + piece);
+                g2_dma16(asb[i] + (int64_t)kt * a_ss, ab + piece);
+                g2_dma16(wsb[i] + (int64_t)kt * w_ss, wb + piece);
             }
             if constexpr (XR) {
-                if (wave == 0) g2_dma16(xsrc + (int64_t)kt * GM_BK, ab + 32 * 1024);
+                if (wave == 0) g2_dma16(xsrc + (int64_t)kt * a_ss, ab + 32 * 1024);
             }
         };
         // touch lines: wave 0 = 64 weight rows (quarter tm & 3 of the 256), wave 1 = 32 activation rows (eighth tn & 7); one line per
@@ -137,12 +157,13 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(vcla_gemm_args a, int
         const bool pf_wave = wave < 2;
         int prow = wave == 0 ? n0 + 64 * (tm & 3) + lane : m0 + 32 * (tn & 7) + (lane & 31);
         if (wave == 0) prow = prow < n_pad ? prow : n_pad - 1; else prow = prow < a.M ? prow : a.M - 1;
-        const bf16_t* pfsrc = wave == 0 ? Wg + (int64_t)prow * a.K : Ag + (int64_t)prow * a.lda;
+        const char* pfsrc = wave == 0 ? Wb + (int64_t)prow * w_rs : Ab + (int64_t)prow * a_rs;
+        const int64_t pf_ss = wave == 0 ? w_ss : a_ss;
         // (every workgroup touching ALL 512 lines of its own slab -- one touch per wave and K step -- is slower: B = 64 prefill 98.1 vs 92.5 ms,
         // profiles/r03_gemm256_ab.txt run 25: the touches are not free, sharing them across the workgroups of a panel is what pays)
         const unsigned sink = __builtin_amdgcn_readfirstlane(lds_u + 2 * STAGE + (wave & 1) * 256);   // (sink bytes are never read: waves may share them)
         auto touch = [&](int kt) {
-            if (pf_wave) g2_dma4(pfsrc + (int64_t)(kt < nk ? kt : nk - 1) * GM_BK, sink);
+            if (pf_wave) g2_dma4(pfsrc + (int64_t)(kt < nk ? kt : nk - 1) * pf_ss, sink);
         };
         f32x4_t acc[8][4];
 #pragma unroll
@@ -459,6 +480,7 @@ static int launch_mfma256(const vcla_gemm_args* a, hipStream_t s) {
     static const int pf = getenv("VCLA_GEMM_PF") ? atoi(getenv("VCLA_GEMM_PF")) : 1;
     static const int xr_env = getenv("VCLA_GEMM_XR") ? atoi(getenv("VCLA_GEMM_XR")) : 1;   // 0: 256-row tiles also when M % 257 == 0
     const int nt = tiles_m * tiles_n;
+    if (!(pf && SGB) && (a->A_slab || a->W_slab)) return vcla_fail(VCLA_ERR_BAD_ARG, "gemm: slab-major operands need the direct-to-LDS form of the 256 x 256 kernel (force_kernel 4, VCLA_GEMM_PF=1)");
     if (pf && SGB && a->K >= 3 * GM_BK) {   // force_kernel 5 (SGB = false) stays the plain form: both forms remain under test
         if (xr_env && vcla_gemm_tile257(a)) {   // M = B * 257 (the ViT's token count): 257-row tiles, no ragged tail
             auto kx = gemm_mfma256_kernel<EPI, OutT, SGB, true, 1>;

@@ -36,6 +36,11 @@ __device__ __forceinline__ void gr_dma4(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+__device__ __forceinline__ void gr_dma16_nt(const void* gsrc, unsigned lds_dst) {      // non-temporal: a line one CU reads once should not displace the panel in L2
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 template <int N> __device__ __forceinline__ void gr_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
@@ -48,8 +53,13 @@ __device__ __forceinline__ bf16x8_t gr_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 }
 
 // BM x BN output tile, WM x WN = 8 waves (wave (wm, wn) owns BM/WM rows x BN/WN columns), NS ring stages of KS K-slabs, W8 = fp8 weights
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
+// VAR (experiments, tools/bench_kernels.py ring; VCLA_RING_VAR): bit 0 = DMA statements spread over the MFMA groups of the stage instead of issued in one
+// burst behind the barrier; bit 1 = nt policy on the weight pieces; bits 4.. = timing ablations with GARBAGE results: 16 = no fragment reads / MFMAs
+// (DMA + barriers only), 32 = no weight DMA, 48 = no activation DMA
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
+    constexpr bool SPREAD = (VAR & 1) != 0, WNT = (VAR & 2) != 0;
+    constexpr int ABL = VAR >> 4;
     static_assert(WM * WN == 8 && BM % 64 == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NS >= 3, "tile / wave grid");
     static_assert(EPI != VCLA_EPI_SWIGLU || (BN / WN) % 32 == 0, "SwiGLU pairs (gate, up) tiles inside a wave");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -70,7 +80,15 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
     const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)ring;
     const unsigned sink = lds_u + NS * STAGE;                   // 256 B nobody reads: destination of the dummies
 
-    // ---- sources of this wave's pieces (slab 0), LDS offsets inside a slab
+    // ---- sources of this wave's pieces (slab 0), LDS offsets inside a slab.  Row-major operands: rows lda / K elements apart, K slabs 128 B
+    // (fp8: 64 B) apart; slab-major operands ([K/64][rows][64], vcla_gemm_args.A_slab / W_slab / W_q8_slab): rows 128 B apart, slabs rows * 128 B
+    // apart -- a piece's 8 (16) rows are then ONE contiguous 1 KiB, which is what the DMA path moves at full rate
+    const char* Ab = (const char*)(a.A_slab ? a.A_slab : a.A);
+    const int64_t a_rs = a.A_slab ? 128 : a.lda * 2, a_ss = a.A_slab ? a.a_slab_rows * 128 : 128;
+    constexpr int W_ROW = W8 ? 64 : 128;                      // bytes of one weight row inside a K slab
+    const bool wslab = W8 ? a.W_q8_slab != nullptr : a.W_slab != nullptr;
+    const char* Wb = (const char*)(W8 ? (wslab ? a.W_q8_slab : a.W_q8) : (wslab ? a.W_slab : a.W));
+    const int64_t w_rs = wslab ? W_ROW : (int64_t)a.K * (W8 ? 1 : 2), w_ss = wslab ? (int64_t)n_pad * W_ROW : W_ROW;
     const char* asrc[IA];
     const char* wsrc[IW];
     bool wreal[IW];
@@ -80,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);          // source-side swizzle (involution shared with lds_off)
         int am = m0 + row;
         am = am < a.M ? am : a.M - 1;
-        asrc[i] = (const char*)a.A + ((int64_t)am * a.lda + chunk * 8) * 2;
+        asrc[i] = Ab + (int64_t)am * a_rs + chunk * 16;
     }
 #pragma unroll
     for (int i = 0; i < IW; ++i) {
@@ -92,36 +110,37 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
             const int c = (lane & 3) ^ ((row >> 2) & 3);          // 16-byte chunk of the 64-byte slab row this lane fetches
             int wr = n0 + row;
             wr = wr < n_pad ? wr : n_pad - 1;
-            wsrc[i] = (const char*)a.W_q8 + (int64_t)wr * a.K + c * 16;
+            wsrc[i] = Wb + (int64_t)wr * w_rs + c * 16;
         } else {
             const int row = qq * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             int wr = n0 + row;
             wr = wr < n_pad ? wr : n_pad - 1;
-            wsrc[i] = (const char*)a.W + ((int64_t)wr * a.K + chunk * 8) * 2;
+            wsrc[i] = Wb + (int64_t)wr * w_rs + chunk * 16;
         }
     }
     const int nslab = a.K / GM_BK;
-    constexpr int W_STEP = W8 ? 64 : 128;                       // bytes per K slab along a weight row
-    // stage `st` (K slabs st * KS ...) into ring buffer `buf`: PP instructions, always
-    auto issue = [&](int st, int buf) {
-        const unsigned base = lds_u + buf * STAGE;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const int slab = st * KS + k;
-            const bool live = slab < nslab;
-            const unsigned sb = base + k * SLAB;
-#pragma unroll
-            for (int i = 0; i < IA; ++i) {
-                if (live) gr_dma16(asrc[i] + (int64_t)slab * 128, sb + (unsigned)(wave + 8 * i) * 1024u);
-                else gr_dma4(asrc[i], sink);
-            }
-#pragma unroll
-            for (int i = 0; i < IW; ++i) {
-                if (live && wreal[i]) gr_dma16(wsrc[i] + (int64_t)slab * W_STEP, sb + A_BYTES + (unsigned)(wave + 8 * i) * 1024u);
-                else gr_dma4(wsrc[i], sink);
-            }
+    // DMA slot `idx` (0 .. PP - 1; compile-time after unrolling) of stage `st` into ring buffer `buf`: slab k = idx / (IA + IW), then IA activation
+    // pieces and IW weight pieces.  Every slot issues exactly ONE instruction (absent pieces / the K tail: a 4-byte dummy into the sink).
+    auto issue_slot = [&](int idx, int st, int buf) {
+        const int k = idx / (IA + IW), r = idx % (IA + IW);
+        const int slab = st * KS + k;
+        const bool live = slab < nslab;
+        const unsigned sb = lds_u + buf * STAGE + k * SLAB;
+        if (r < IA) {
+            if (live && ABL != 3) gr_dma16(asrc[r] + (int64_t)slab * a_ss, sb + (unsigned)(wave + 8 * r) * 1024u);
+            else gr_dma4(asrc[r], sink);
+        } else {
+            const int i = r - IA;
+            if (live && wreal[i] && ABL != 2) {
+                if constexpr (WNT) gr_dma16_nt(wsrc[i] + (int64_t)slab * w_ss, sb + A_BYTES + (unsigned)(wave + 8 * i) * 1024u);
+                else gr_dma16(wsrc[i] + (int64_t)slab * w_ss, sb + A_BYTES + (unsigned)(wave + 8 * i) * 1024u);
+            } else gr_dma4(wsrc[i], sink);
         }
+    };
+    auto issue = [&](int st, int buf) {
+#pragma unroll
+        for (int idx = 0; idx < PP; ++idx) issue_slot(idx, st, buf);
     };
 
     f32x4_t acc[MI][NJ];
@@ -139,33 +158,46 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         gr_vmcnt<(NS - 2) * PP>();                              // this wave's pieces of stage st have landed (NS - 2 younger stages may not have)
         __builtin_amdgcn_s_barrier();                          // ... everyone's; and the buffer of stage st - 1 is no longer read
         asm volatile("" ::: "memory");
-        issue(st + NS - 1, buf_i);
+        if constexpr (!SPREAD) issue(st + NS - 1, buf_i);
         const unsigned char* Sb = ring + buf_c * STAGE;
+        constexpr int G = KS * 2 * MI;                          // MFMA groups (NJ MFMAs each) of a stage: the SPREAD form issues PP DMA statements between them
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            if (KS > 1 && st * KS + k >= nslab) break;          // K tail of a multi-slab stage (wave-uniform)
+            const bool have = !(KS > 1 && st * KS + k >= nslab);  // K tail of a multi-slab stage (wave-uniform); the DMA slots are issued regardless
             const unsigned char* As = Sb + k * SLAB;
             const unsigned char* Ws = As + A_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t wf[NJ], af[MI];
+                if (have && ABL != 1) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int row = wn * (BN / WN) + j * 16 + frow;
-                    if constexpr (W8) {
-                        const int cg = kk * 2 + (fch >> 1);
-                        const uint2 raw = *reinterpret_cast<const uint2*>(Ws + row * 64 + ((cg ^ ((row >> 2) & 3)) << 4) + (fch & 1) * 8);
-                        wf[j] = gr_fp8x8_to_bf16x8(raw.x, raw.y);
-                    } else {
-                        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(row, kk * 4 + fch));
+                    for (int j = 0; j < NJ; ++j) {
+                        const int row = wn * (BN / WN) + j * 16 + frow;
+                        if constexpr (W8) {
+                            const int cg = kk * 2 + (fch >> 1);
+                            const uint2 raw = *reinterpret_cast<const uint2*>(Ws + row * 64 + ((cg ^ ((row >> 2) & 3)) << 4) + (fch & 1) * 8);
+                            wf[j] = gr_fp8x8_to_bf16x8(raw.x, raw.y);
+                        } else {
+                            wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(row, kk * 4 + fch));
+                        }
                     }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * (BM / WM) + i * 16 + frow, kk * 4 + fch));
                 }
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * (BM / WM) + i * 16 + frow, kk * 4 + fch));
+                for (int i = 0; i < MI; ++i) {
+                    if (have && ABL != 1) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                    if constexpr (SPREAD) {                      // this group's share of the stage's PP DMA statements
+                        constexpr int dummy = 0; (void)dummy;
+                        const int g = (k * 2 + kk) * MI + i;
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                        for (int idx = 0; idx < PP; ++idx)
+                            if (idx * G / PP == g) issue_slot(idx, st + NS - 1, buf_i);
+                    }
+                }
             }
         }
         asm volatile("" ::: "memory");                          // the fragment reads stay on this side of the next barrier
@@ -177,11 +209,26 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
 }
 
 // ------------------------------------------------------------------ host side
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, int VAR = 0>
 static int launch_ring_cfg(const vcla_gemm_args* a, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * KS * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256;
     static_assert(lds <= 160 * 1024, "ring exceeds the 160 KiB of a CU");
-    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8>;
+#ifdef VCLA_RING_EXPERIMENTS
+    if constexpr (VAR == 0 && sizeof(OutT) == 2 && !W8) {       // experiment builds: VCLA_RING_VAR selects a variant of the bf16 instances at run time
+        const char* e = getenv("VCLA_RING_VAR");
+        switch (e ? atoi(e) : 0) {
+            case 1: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 1>(a, s);
+            case 2: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 2>(a, s);
+            case 3: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 3>(a, s);
+            case 16: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 16>(a, s);
+            case 17: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 17>(a, s);
+            case 32: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 32>(a, s);
+            case 48: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 48>(a, s);
+            default: break;
+        }
+    }
+#endif
+    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, VAR>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
@@ -221,7 +268,7 @@ static int launch_ring(const vcla_gemm_args* a, hipStream_t s) {
 
 // entry point for gemm.hip's dispatch (kernel 11); arguments validated there
 int vcla_gemm_ring_launch(const vcla_gemm_args* a, hipStream_t s) {
-    const bool w8 = a->W_q8 != nullptr;
+    const bool w8 = a->W_q8 != nullptr || a->W_q8_slab != nullptr;
     if (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32) return w8 ? launch_ring<VCLA_EPI_SWIGLU, bf16_t, true>(a, s) : launch_ring<VCLA_EPI_SWIGLU, bf16_t, false>(a, s);
     if (a->epilogue == VCLA_EPI_NONE) {
         if (a->out_f32) return w8 ? launch_ring<VCLA_EPI_NONE, float, true>(a, s) : launch_ring<VCLA_EPI_NONE, float, false>(a, s);     // lm_head: fp32 logits

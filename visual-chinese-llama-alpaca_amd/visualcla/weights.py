@@ -62,6 +62,20 @@ def from_fragment_major(wf: torch.Tensor) -> torch.Tensor:
     return wf.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().view(nt * 16, ks * 32)
 
 
+def to_slab_major(x: torch.Tensor) -> torch.Tensor:
+    """[rows, K] -> [K/64, rows, 64] (vcla_gemm_args.A_slab / W_slab / W_q8_slab): the K slab of any 8 consecutive rows (fp8: 16) is one
+    contiguous 1 KiB -- what a single LDS-DMA wave instruction moves at full rate (profiles/r05_l2_intake.txt: ~50 B/clk/CU against ~19 for the
+    8-row x 128-byte gather out of a row-major matrix).  Any element type."""
+    r, k = x.shape
+    assert k % 64 == 0
+    return x.view(r, k // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def from_slab_major(xs: torch.Tensor) -> torch.Tensor:
+    ks, r, _ = xs.shape
+    return xs.permute(1, 0, 2).contiguous().view(r, ks * 64)
+
+
 def quantize_fp8_rows(w_packed: torch.Tensor):
     """bf16 [N_pad, K] -> (uint8 [N_pad, K] holding OCP e4m3fn bits, fp32 per-row scale [N_pad]); W ~= q * scale[row]."""
     wf = w_packed.float()
