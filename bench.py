@@ -97,7 +97,7 @@ def _event_time(fn, reps: int):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-PROFILE_ROUNDS = ("r04", "r03", "r02")     # committed rocprofv3 summaries, newest first
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")     # committed rocprofv3 summaries, newest first
 
 
 def _pmc_traffic(stem: str = "pmc_gemv1p"):

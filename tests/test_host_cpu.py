@@ -340,12 +340,13 @@ def test_no_compute_kernel_uses_scratch():
     assert not bad, f"kernels with a private segment (spills / scratch arrays): {bad}"
 
 
-def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
-    """attn_vit_dma_kernel loads its Q fragments with inline-asm `global_load_dwordx4` that hipcc does not count (the hand-counted vmcnt in
-    front of key tile 0 completes them together with the LDS-DMA pieces).  hipcc treats an asm load's destination as written at the end of
-    the statement, so nothing but register allocation keeps it from copying / spilling / reusing those registers before the data lands
-    (cdna_hip_programming.md section 5).  This test audits the SHIPPED code object: between the 8 loads and the `s_waitcnt vmcnt(12)` no
-    instruction may name one of their 32 destination registers."""
+@pytest.mark.parametrize("sym,vm", [("_Z19attn_vit_dma_kernel14vcla_attn_args", 12), ("_Z20attn_vit_long_kernelILi9EEv14vcla_attn_args", 17)])
+def test_vit_attention_asm_register_loads_are_untouched_until_their_wait(sym, vm):
+    """attn_vit_dma_kernel (257 tokens) and attn_vit_long_kernel (577 tokens) load their Q fragments with inline-asm `global_load_dwordx4` that hipcc
+    does not count (the hand-counted vmcnt in front of key tile 0 completes them together with the LDS-DMA pieces).  hipcc treats an asm load's
+    destination as written at the end of the statement, so nothing but register allocation keeps it from copying / spilling / reusing those
+    registers before the data lands (cdna_hip_programming.md section 5).  This test audits the SHIPPED code object: between the 8 loads and the
+    `s_waitcnt vmcnt(12 / 17)` no instruction may name one of their 32 destination registers."""
     import re
     import subprocess
     import tempfile
@@ -353,7 +354,6 @@ def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
     so = os.path.join(ROOT, "visual-chinese-llama-alpaca_amd", "visualcla", "libvisualcla_hip.so")
     if not (os.path.exists(so) and all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump", "llvm-readelf"))):
         pytest.skip("library not built or ROCm LLVM tools absent")
-    sym = "_Z19attn_vit_dma_kernel14vcla_attn_args"
     with tempfile.TemporaryDirectory() as td:
         fb = os.path.join(td, "fat.bin")
         subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", so])
@@ -371,7 +371,7 @@ def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
             dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--mcpu=gfx950", f"--disassemble-symbols={sym}", co], capture_output=True, text=True, check=True).stdout
             body = dis[dis.index(f"<{sym}>:"):]
             break
-    assert body is not None, "attn_vit_dma_kernel not found in the library"
+    assert body is not None, f"{sym} not found in the library"
     lines = [ln.split("//")[0] for ln in body.splitlines()[1:]]
     loads, first, wait = [], None, None
     for i, ln in enumerate(lines):
@@ -379,7 +379,7 @@ def test_vit_attention_asm_register_loads_are_untouched_until_their_wait():
         if m and wait is None:
             loads.append((int(m.group(1)), int(m.group(2))))
             first = i if first is None else first
-        if wait is None and re.search(r"s_waitcnt vmcnt\(12\)", ln):
+        if wait is None and re.search(rf"s_waitcnt vmcnt\({vm}\)", ln):
             wait = i
     assert len(loads) == 8 and wait is not None and first < wait, (loads, first, wait)
     regs = {r for a, b in loads for r in range(a, b + 1)}

@@ -584,9 +584,11 @@ __global__ __launch_bounds__(NWM * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 // the tile loop consumes them, and vmcnt is counted by hand: tile t is computed once the wave's own pieces of tile t have landed and the
 // workgroup has met at a bare s_barrier, while the later tiles are still in flight.  LDS images are lane-linear per DMA instruction, so the
 // bank swizzles of fa_k_off / fa_v_off are applied on the SOURCE side (the lane of slot p fetches the chunk that belongs there).
-// Q takes the same road: each wave DMAs its own 64 query rows (8 KiB) into the LDS area of key tiles 2 / 3, reads its MFMA fragments out
-// of it (swizzled like K: conflict-free ds_read_b128), and only then are tiles 2 and 3 requested -- no register-destination load, whose
-// completion the compiler could not see, anywhere.  The last key / value / query rows ride in three padded 1 KiB pieces.
+// The wave's own Q fragments are the one exception: eight inline-asm REGISTER loads ("=v"), issued first and completed by the same counted wait
+// as key tile 0, whose statement names every destination "+v" (cdna_hip_programming.md section 5, form (ii)); hipcc treats the destinations as
+// written at the load statement, so the shipped code object is audited for any use of them before the wait
+// (tests/test_host_cpu.py::test_vit_attention_asm_register_loads_are_untouched_until_their_wait) and for an empty private segment -- a spill of one
+// of them before the wait would store stale bits.  The last key / value / query rows ride in three padded 1 KiB pieces.
 __device__ __forceinline__ void fa_dma16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -743,8 +745,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s], o[qt][dt], 0, 0, 0);
             }
     };
-    // DMA queue of a wave now: [tile 0: 4][tile 1: 4][last rows: 1][tile 2: 4][tile 3: 4]; tile t is ready once nothing older than the
-    // pieces behind it is outstanding (vmcnt retires in order) and every wave has said so
     // VMEM queue of a wave: [Q: 8][last rows: 1][tile 0: 4][tile 1: 4][tile 2: 4][tile 3: 4]; vmcnt retires in order, so "at most 12 outstanding"
     // means Q, the last rows and this wave's pieces of tile 0 have landed; every wave says so at the barrier
     asm volatile("s_waitcnt vmcnt(12)"
@@ -1275,7 +1275,7 @@ bool vcla_attention_mfma_supported(const vcla_attn_args* a) {
 int vcla_attention_mfma(const vcla_attn_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const int nw_env = getenv("VCLA_ATTN_MFMA_NW") ? atoi(getenv("VCLA_ATTN_MFMA_NW")) : 0;   // A/B runs: force 4
-    // ViT self-attention (65 / 129 / 257 tokens, d = 64) with at least half a round of workgroups: the whole-sequence kernel
+    // ViT self-attention (65 / 257 / 577 tokens, d = 64) with at least half a round of workgroups: the whole-sequence kernels
     static const int vit_env = getenv("VCLA_ATTN_VIT") ? atoi(getenv("VCLA_ATTN_VIT")) : 1;           // A/B runs: 0 = the tile-by-tile kernel
     if (vit_env && a->force_kernel != 2 && attn_vit_shape(a) && (int64_t)a->B * a->H >= 128) return vcla_attention_vit(a, stream);
     // waves per workgroup: bidirectional sequences longer than one 128-row block go 288 rows at a time (ViT-L/14 224 px: the

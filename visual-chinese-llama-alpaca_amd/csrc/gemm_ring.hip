@@ -15,10 +15,10 @@
 //     16 rows x 64 B) dealt round-robin to the 8 waves, bank-conflict swizzle applied on the SOURCE address (as gemm_mfma256.hip);
 //   * NS stages: NS - 1 in flight while one is consumed; all DMA from inline asm with hand-counted vmcnt, ONE barrier per stage; every wave
 //     issues exactly PP DMA instructions per stage (absent pieces and the K tail are 4-byte dummies into a sink) so the count is a literal;
-//   * fp8 (e4m3fn) weights (W8A16, BASELINE configs[4]): the 1-byte rows are staged as they are (half the LDS and HBM bytes), fragments are read
-//     with ds_read_b64 and widened to bf16 in registers (exact), the per-row scale is applied in the epilogue -- the same function of the
-//     dequantised weights as the M <= 128 decode kernels compute.
-// Operands are the plain row-major matrices (A [M, lda], W [N_pad, K]); epilogue = gemm_epilogue.h (bias / residual / SwiGLU / fp8 scales).
+//   * fp8 (e4m3fn) weights (W8A16, BASELINE configs[4]): the 1-byte rows travel as they are (half the HBM and DMA bytes), are widened to bf16 ONCE per
+//     stage by the workgroup (exact) into the image the fragment reads use, and the per-row scale is applied in the epilogue -- the same function of
+//     the dequantised weights as the M <= 128 decode kernels compute.
+// Operands are the plain row-major matrices (A [M, lda], W [N_pad, K]) or their slab-major twins; epilogue = gemm_epilogue.h (bias / residual / SwiGLU / fp8 scales).
 #include "vcla_common.h"
 #include "gemm_epilogue.h"
 #include "gemm_tiles.h"
@@ -36,11 +36,6 @@ __device__ __forceinline__ void gr_dma4(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void gr_dma16_nt(const void* gsrc, unsigned lds_dst) {      // non-temporal: a line one CU reads once should not displace the panel in L2
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 template <int N> __device__ __forceinline__ void gr_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 8 OCP fp8 (e4m3fn) values in two dwords -> one bf16x8 MFMA operand (exact: e4m3 fits in bf16)
@@ -52,37 +47,47 @@ __device__ __forceinline__ bf16x8_t gr_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
     return __builtin_bit_cast(bf16x8_t, p);
 }
 
-// BM x BN output tile, WM x WN = 8 waves (wave (wm, wn) owns BM/WM rows x BN/WN columns), NS ring stages of KS K-slabs, W8 = fp8 weights
-// VAR (experiments, tools/bench_kernels.py ring; VCLA_RING_VAR): bit 0 = DMA statements spread over the MFMA groups of the stage instead of issued in one
-// burst behind the barrier; bit 1 = nt policy on the weight pieces; bits 4.. = timing ablations with GARBAGE results: 16 = no fragment reads / MFMAs
-// (DMA + barriers only), 32 = no weight DMA, 48 = no activation DMA
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, int VAR = 0>
+// BM x BN output tile, WM x WN = 8 waves (wave (wm, wn) owns BM/WM rows x BN/WN columns), NS ring stages of KS K-slabs, W8 = fp8 weights.
+// LDS: [A ring: NS stages][W ring: NS + WLEAD stages][W8 only: two bf16 images of a stage's weights][sink].
+// W8: the e4m3 rows travel as they are (half the bytes) one stage AHEAD of the activations (WLEAD = 1); behind the barrier of stage st every wave
+// widens 1/8 of stage st + 1's weights to bf16 ONCE (exact), into the image the fragment reads of stage st + 1 will use -- the first form of this
+// kernel widened every fragment in every wave that read it (8 x the cvt work, on the critical path of each MFMA group): gate/up 78 us at M = 256
+// against 62 us for the bf16 weights (profiles/r05_ring_microbench.txt).
+// Measured and dropped (experiment build, profiles/r05_ring_variants.txt): the DMA statements spread over the MFMA groups instead of one burst behind the
+// barrier (-0 .. 7 %, inside the noise in the model), nt policy on the weight pieces (equal); with the fragment reads and MFMAs REMOVED the kernel
+// is 3 % faster, without the weight DMA 12 %, without the activation DMA 0 %: the stage cadence is set by the round trip of NS - 1 stages in flight
+// (~90 - 130 KiB per CU against ~2 us under load), not by issue, compute or either operand alone.
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
-    constexpr bool SPREAD = (VAR & 1) != 0, WNT = (VAR & 2) != 0;
-    constexpr int ABL = VAR >> 4;
     static_assert(WM * WN == 8 && BM % 64 == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NS >= 3, "tile / wave grid");
     static_assert(EPI != VCLA_EPI_SWIGLU || (BN / WN) % 32 == 0, "SwiGLU pairs (gate, up) tiles inside a wave");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+    constexpr int WLEAD = W8 ? 1 : 0;                          // stages the weight stream runs ahead of the activations
     constexpr int A_BYTES = BM * 128;                          // one K slab of the activations: BM rows x 64 bf16
-    constexpr int W_BYTES = W8 ? BN * 64 : BN * 128;           // ... of the weights
-    constexpr int SLAB = A_BYTES + W_BYTES, STAGE = KS * SLAB;
+    constexpr int W_BYTES = W8 ? BN * 64 : BN * 128;           // ... of the weights as they travel
+    constexpr int WB_BYTES = BN * 128;                         // ... of the weights as bf16
+    constexpr int A_STAGE = KS * A_BYTES, W_STAGE = KS * W_BYTES;
+    constexpr int W_RING = NS * A_STAGE;                       // LDS offsets
+    constexpr int W_BF = W_RING + (NS + WLEAD) * W_STAGE;
+    constexpr int SINK = W_BF + (W8 ? 2 * KS * WB_BYTES : 0);
     constexpr int IA = BM / 64;                                // A pieces per wave and slab (BM / 8 pieces of 1 KiB over 8 waves)
     constexpr int PW = W_BYTES / 1024;                         // W pieces per slab
     constexpr int IW = (PW + 7) / 8;                           // ... per wave (the last one may be absent: dummy)
     constexpr int PP = KS * (IA + IW);                         // DMA instructions per wave and stage, exactly
     constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
     static_assert(W_BYTES % 1024 == 0, "whole pieces");
+    static_assert((NS - 1) * PP <= 63, "vmcnt range");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int tm, tn;
     tile_assign(blockIdx.x, tiles_m, tiles_n, tiles_m, tm, tn);      // consecutive blocks of an XCD: the row tiles of ONE column tile (they share its W rows)
     const int m0 = tm * BM, n0 = tn * BN;
     const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)ring;
-    const unsigned sink = lds_u + NS * STAGE;                   // 256 B nobody reads: destination of the dummies
+    const unsigned sink = lds_u + SINK;                         // 256 B nobody reads: destination of the dummies
 
     // ---- sources of this wave's pieces (slab 0), LDS offsets inside a slab.  Row-major operands: rows lda / K elements apart, K slabs 128 B
     // (fp8: 64 B) apart; slab-major operands ([K/64][rows][64], vcla_gemm_args.A_slab / W_slab / W_q8_slab): rows 128 B apart, slabs rows * 128 B
-    // apart -- a piece's 8 (16) rows are then ONE contiguous 1 KiB, which is what the DMA path moves at full rate
+    // apart -- a piece's 8 (16) rows are then ONE contiguous 1 KiB (measured: +2 - 8 % here, profiles/r05_ring_microbench.txt)
     const char* Ab = (const char*)(a.A_slab ? a.A_slab : a.A);
     const int64_t a_rs = a.A_slab ? 128 : a.lda * 2, a_ss = a.A_slab ? a.a_slab_rows * 128 : 128;
     constexpr int W_ROW = W8 ? 64 : 128;                      // bytes of one weight row inside a K slab
@@ -106,11 +111,10 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         wreal[i] = q < PW;
         const int qq = wreal[i] ? q : 0;
         if constexpr (W8) {
-            const int row = qq * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);          // 16-byte chunk of the 64-byte slab row this lane fetches
+            const int row = qq * 16 + (lane >> 2);                // 16 rows x 64 B per piece, stored LINEAR (the widening pass reads 16 B per lane in order)
             int wr = n0 + row;
             wr = wr < n_pad ? wr : n_pad - 1;
-            wsrc[i] = Wb + (int64_t)wr * w_rs + c * 16;
+            wsrc[i] = Wb + (int64_t)wr * w_rs + (lane & 3) * 16;
         } else {
             const int row = qq * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
@@ -120,27 +124,45 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         }
     }
     const int nslab = a.K / GM_BK;
-    // DMA slot `idx` (0 .. PP - 1; compile-time after unrolling) of stage `st` into ring buffer `buf`: slab k = idx / (IA + IW), then IA activation
-    // pieces and IW weight pieces.  Every slot issues exactly ONE instruction (absent pieces / the K tail: a 4-byte dummy into the sink).
-    auto issue_slot = [&](int idx, int st, int buf) {
-        const int k = idx / (IA + IW), r = idx % (IA + IW);
-        const int slab = st * KS + k;
-        const bool live = slab < nslab;
-        const unsigned sb = lds_u + buf * STAGE + k * SLAB;
-        if (r < IA) {
-            if (live && ABL != 3) gr_dma16(asrc[r] + (int64_t)slab * a_ss, sb + (unsigned)(wave + 8 * r) * 1024u);
-            else gr_dma4(asrc[r], sink);
-        } else {
-            const int i = r - IA;
-            if (live && wreal[i] && ABL != 2) {
-                if constexpr (WNT) gr_dma16_nt(wsrc[i] + (int64_t)slab * w_ss, sb + A_BYTES + (unsigned)(wave + 8 * i) * 1024u);
-                else gr_dma16(wsrc[i] + (int64_t)slab * w_ss, sb + A_BYTES + (unsigned)(wave + 8 * i) * 1024u);
-            } else gr_dma4(wsrc[i], sink);
+    // issue group j = {activations of stage j, weights of stage j + WLEAD}: PP instructions, always (absent pieces, stages outside [0, nst): 4-byte
+    // dummies into the sink).  buf_a / buf_w: the ring buffers the two stages go to.
+    auto issue = [&](int j, int buf_a, int buf_w) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int slab_a = j * KS + k, slab_w = (j + WLEAD) * KS + k;
+            const bool live_a = j >= 0 && slab_a < nslab, live_w = slab_w < nslab;
+            const unsigned ab = lds_u + buf_a * A_STAGE + k * A_BYTES, wb = lds_u + W_RING + buf_w * W_STAGE + k * W_BYTES;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                if (live_a) gr_dma16(asrc[i] + (int64_t)slab_a * a_ss, ab + (unsigned)(wave + 8 * i) * 1024u);
+                else gr_dma4(asrc[i], sink);
+            }
+#pragma unroll
+            for (int i = 0; i < IW; ++i) {
+                if (live_w && wreal[i]) gr_dma16(wsrc[i] + (int64_t)slab_w * w_ss, wb + (unsigned)(wave + 8 * i) * 1024u);
+                else gr_dma4(wsrc[i], sink);
+            }
         }
     };
-    auto issue = [&](int st, int buf) {
+    // W8: widen this wave's share of the e4m3 weights in W-ring buffer `buf_w` into bf16 image `img` (unit u = 16 bytes = 16 weights of one row:
+    // (slab, row, 16-k chunk c) -> the two 16-byte chunks 2c, 2c + 1 of that row in the [rows][128 B] image the fragment reads use)
+    auto widen = [&](int buf_w, int img) {
+        if constexpr (W8) {
+            constexpr int UNITS = KS * BN * 4;
+            const unsigned char* src = ring + W_RING + buf_w * W_STAGE;
+            unsigned char* dst = ring + W_BF + img * (KS * WB_BYTES);
 #pragma unroll
-        for (int idx = 0; idx < PP; ++idx) issue_slot(idx, st, buf);
+            for (int p = 0; p < (UNITS + 511) / 512; ++p) {
+                const int u = p * 512 + wave * 64 + lane;
+                if (u < UNITS) {
+                    const int k = u / (BN * 4), r = (u / 4) % BN, c = u & 3;
+                    const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(src + u * 16);
+                    unsigned char* row = dst + k * WB_BYTES;
+                    *reinterpret_cast<bf16x8_t*>(row + lds_off(r, 2 * c)) = gr_fp8x8_to_bf16x8(raw.x, raw.y);
+                    *reinterpret_cast<bf16x8_t*>(row + lds_off(r, 2 * c + 1)) = gr_fp8x8_to_bf16x8(raw.z, raw.w);
+                }
+            }
+        }
     };
 
     f32x4_t acc[MI][NJ];
@@ -151,84 +173,59 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
     const int frow = lane & 15, fch = lane >> 4;
     const int nst = (nslab + KS - 1) / KS;
 
+    // ---- prologue: groups -WLEAD .. NS - 2 (W8: group -1 carries the weights of stage 0 alone, which are widened before the loop)
+    int buf_a = 0, buf_w = 0;                                   // ring buffers of the NEXT group to issue
+    auto step = [&](int& b, int n) { b = b + 1 == n ? 0 : b + 1; };
+    if constexpr (W8) { issue(-1, 0, buf_w); step(buf_w, NS + WLEAD); }
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s, s);
-    int buf_c = 0, buf_i = NS - 1;
-    for (int st = 0; st < nst; ++st) {
-        gr_vmcnt<(NS - 2) * PP>();                              // this wave's pieces of stage st have landed (NS - 2 younger stages may not have)
-        __builtin_amdgcn_s_barrier();                          // ... everyone's; and the buffer of stage st - 1 is no longer read
+    for (int s = 0; s < NS - 1; ++s) { issue(s, buf_a, buf_w); step(buf_a, NS); step(buf_w, NS + WLEAD); }
+    if constexpr (W8) {
+        gr_vmcnt<(NS - 1) * PP>();                              // group -1 has landed (NS - 1 younger groups may not have)
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (!SPREAD) issue(st + NS - 1, buf_i);
-        const unsigned char* Sb = ring + buf_c * STAGE;
-        constexpr int G = KS * 2 * MI;                          // MFMA groups (NJ MFMAs each) of a stage: the SPREAD form issues PP DMA statements between them
+        widen(0, 0);
+    }
+    int cur_a = 0, cur_w = WLEAD;                               // A ring buffer of stage st; W ring buffer of stage st + WLEAD
+    for (int st = 0; st < nst; ++st) {
+        gr_vmcnt<(NS - 2) * PP>();                              // this wave's pieces of group st have landed (NS - 2 younger groups may not have)
+        __builtin_amdgcn_s_barrier();                          // ... everyone's; the buffers of stage st - 1 are no longer read; (W8) the bf16 image of stage st is complete
+        asm volatile("" ::: "memory");
+        issue(st + NS - 1, buf_a, buf_w);
+        step(buf_a, NS); step(buf_w, NS + WLEAD);
+        if constexpr (W8) widen(cur_w, (st + 1) & 1);           // weights of stage st + 1 -> the other image (read after the NEXT barrier)
+        const unsigned char* Ab_s = ring + cur_a * A_STAGE;
+        const unsigned char* Wb_s = W8 ? ring + W_BF + (st & 1) * (KS * WB_BYTES) : ring + W_RING + cur_w * W_STAGE;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const bool have = !(KS > 1 && st * KS + k >= nslab);  // K tail of a multi-slab stage (wave-uniform); the DMA slots are issued regardless
-            const unsigned char* As = Sb + k * SLAB;
-            const unsigned char* Ws = As + A_BYTES;
+            if (KS > 1 && st * KS + k >= nslab) break;          // K tail of a multi-slab stage (wave-uniform)
+            const unsigned char* As = Ab_s + k * A_BYTES;
+            const unsigned char* Ws = Wb_s + k * WB_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t wf[NJ], af[MI];
-                if (have && ABL != 1) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int row = wn * (BN / WN) + j * 16 + frow;
-                        if constexpr (W8) {
-                            const int cg = kk * 2 + (fch >> 1);
-                            const uint2 raw = *reinterpret_cast<const uint2*>(Ws + row * 64 + ((cg ^ ((row >> 2) & 3)) << 4) + (fch & 1) * 8);
-                            wf[j] = gr_fp8x8_to_bf16x8(raw.x, raw.y);
-                        } else {
-                            wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(row, kk * 4 + fch));
-                        }
-                    }
+                for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * (BN / WN) + j * 16 + frow, kk * 4 + fch));
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * (BM / WM) + i * 16 + frow, kk * 4 + fch));
-                }
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * (BM / WM) + i * 16 + frow, kk * 4 + fch));
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    if (have && ABL != 1) {
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                    }
-                    if constexpr (SPREAD) {                      // this group's share of the stage's PP DMA statements
-                        constexpr int dummy = 0; (void)dummy;
-                        const int g = (k * 2 + kk) * MI + i;
-#pragma unroll
-                        for (int idx = 0; idx < PP; ++idx)
-                            if (idx * G / PP == g) issue_slot(idx, st + NS - 1, buf_i);
-                    }
-                }
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
             }
         }
-        asm volatile("" ::: "memory");                          // the fragment reads stay on this side of the next barrier
-        buf_c = buf_c + 1 == NS ? 0 : buf_c + 1;
-        buf_i = buf_i + 1 == NS ? 0 : buf_i + 1;
+        asm volatile("" ::: "memory");                          // the fragment reads / image writes stay on this side of the next barrier
+        step(cur_a, NS); step(cur_w, NS + WLEAD);
     }
     gr_vmcnt<0>();                                              // no DMA (the tail's dummies) may land in LDS after the workgroup has given it up
     gemm_epilogue<EPI, OutT, MI, NJ, W8>(a, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 // ------------------------------------------------------------------ host side
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, int VAR = 0>
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
 static int launch_ring_cfg(const vcla_gemm_args* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)NS * KS * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256;
+    constexpr size_t lds = (size_t)NS * KS * BM * 128 + (size_t)(NS + (W8 ? 1 : 0)) * KS * (W8 ? BN * 64 : BN * 128) + (W8 ? (size_t)2 * KS * BN * 128 : 0) + 256;
     static_assert(lds <= 160 * 1024, "ring exceeds the 160 KiB of a CU");
-#ifdef VCLA_RING_EXPERIMENTS
-    if constexpr (VAR == 0 && sizeof(OutT) == 2 && !W8) {       // experiment builds: VCLA_RING_VAR selects a variant of the bf16 instances at run time
-        const char* e = getenv("VCLA_RING_VAR");
-        switch (e ? atoi(e) : 0) {
-            case 1: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 1>(a, s);
-            case 2: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 2>(a, s);
-            case 3: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 3>(a, s);
-            case 16: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 16>(a, s);
-            case 17: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 17>(a, s);
-            case 32: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 32>(a, s);
-            case 48: return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, 48>(a, s);
-            default: break;
-        }
-    }
-#endif
-    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, VAR>;
+    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
@@ -256,13 +253,13 @@ static int ring_cfg(const vcla_gemm_args* a) {
 
 template <int EPI, typename OutT, bool W8>
 static int launch_ring(const vcla_gemm_args* a, hipStream_t s) {
-    // NS: as many stages as 160 KiB hold (fp8 weights: smaller slabs -> one more stage)
+    // NS: as many stages as 160 KiB hold (fp8 weights: their ring is one stage deeper and two bf16 images of a stage sit beside it)
     const int cfg = ring_cfg(a);
-    if (cfg == 1) return launch_ring_cfg<EPI, OutT, 256, 96, 8, 1, W8 ? 4 : 3, 1, W8>(a, s);
+    if (cfg == 1) return launch_ring_cfg<EPI, OutT, 256, 96, 8, 1, 3, 1, W8>(a, s);
     if constexpr (EPI == VCLA_EPI_SWIGLU) return vcla_fail(VCLA_ERR_BAD_ARG, "gemm: the SwiGLU ring tile is 256 x 96");
     else {
-        if (cfg == 2) return launch_ring_cfg<EPI, OutT, 128, 96, 4, 2, W8 ? 6 : 5, 1, W8>(a, s);
-        return launch_ring_cfg<EPI, OutT, 64, 64, 4, 2, W8 ? 5 : 4, 2, W8>(a, s);
+        if (cfg == 2) return launch_ring_cfg<EPI, OutT, 128, 96, 4, 2, 5, 1, W8>(a, s);
+        return launch_ring_cfg<EPI, OutT, 64, 64, 4, 2, 4, 2, W8>(a, s);
     }
 }
 
