@@ -69,7 +69,9 @@ __global__ __launch_bounds__((NA + NW) * 64) void intake_kernel(Args a) {
         long long c = wave;
         int pass = 0;
         auto next = [&]() { c += NA; if (c >= chunks) { c -= chunks; ++pass; } };
-        auto more = [&]() { return NW > 0 ? (__hip_atomic_load(&stream_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) : (pass < a.passes); };
+        // beside a stream: until the stream of this workgroup ends -- but never more than 4096 passes (a starved stream must not turn the probe into a hang:
+        // the first run of this tool sat in the 8-wave x 8-load configuration until its time limit)
+        auto more = [&]() { return NW > 0 ? (pass < 4096 && __hip_atomic_load(&stream_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) : (pass < a.passes); };
         if constexpr (!DMA) {
             u32x4_t b0[L], b1[L];
 #pragma unroll
@@ -229,8 +231,7 @@ int main(int argc, char** argv) {
     for (long long pk : {512LL, 1408LL, 2048LL}) {
         a.panel_kb = pk; a.w_kb_per_wg = 5632;
 #define BESIDE(NA, L, NW) run<NA, L, NW, false>("beside stream", a, grid, out); run<NA, L, NW, true>("beside stream", a, grid, out);
-        BESIDE(2, 4, 4) BESIDE(4, 4, 4) BESIDE(4, 8, 4) BESIDE(8, 4, 4) BESIDE(8, 8, 4) BESIDE(4, 4, 8) BESIDE(8, 4, 8)
-        run<12, 4, 4, false>("beside stream", a, grid, out);
+        BESIDE(2, 4, 4) BESIDE(4, 4, 4) BESIDE(4, 8, 4) BESIDE(8, 4, 4) BESIDE(4, 4, 8)
     }
     fprintf(out, "\n## 4. two workgroups per CU (grid = 2 x CUs), panel alone and beside the stream\n");
     a.panel_kb = 2048; a.w_kb_per_wg = 0; a.passes = 10;
