@@ -181,9 +181,9 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
     P = model._packed
     alg_bytes = 2 * I * D * 2
     if M > 64:
-        # 65 - 256 decode rows run on the row-major 128 x 128 MFMA tiles (engine.hip llama_layer, gemm.hip launch_mfma): the weights are still
-        # streamed once per launch, so the bound quoted is HBM; the tile kernel at M = 256 is neither HBM- nor MFMA-bound (46 GF and 180 MB
-        # in ~90 us = 0.5 PF/s and 2 TB/s): every CU re-reads its share of the 2 MB activation panel, DESIGN.md section 5
+        # 65 - 128 decode rows: the split-K panel kernel; 129 - 256: the ring kernel (gemm_ring.hip).  The weights are streamed once per launch, so the
+        # bound quoted is HBM; at M = 256 neither HBM nor MFMA binds (46 GF and 180 MB in ~62 us = 0.74 PF/s and 2.9 TB/s) but what a CU can keep in
+        # flight against the loaded round trip, DESIGN.md section 5 "Round 5"
         x = torch.randn(M, D, device=model.device).to(torch.bfloat16)
         out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
         ws = torch.zeros(64 << 20, dtype=torch.uint8, device=model.device)
@@ -197,7 +197,8 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
         sec = _event_time(run_tiles, n_rep) / L
         achieved = alg_bytes / sec / 1e9
         return {"bound": "hbm", "kernel": (f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM on the fragment-major copy, bf16)" if use_frag else
-                                                 f"vcla_gemm default dispatch on the row-major weights (B={M} gate/up decode GEMM: 128x128 MFMA tiles / panel kernel, bf16)"),
+                                                 (f"gemm_ring_kernel<SWIGLU, 256x96> (B={M} gate/up decode GEMM: full-K tiles fed by an LDS-DMA ring, bf16; the default dispatch for 129 - 256 rows)"
+                                                  if M > 128 else f"vcla_gemm default dispatch on the row-major weights (B={M} gate/up decode GEMM, bf16)")),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L, "mfma_tflops": round(2.0 * M * 2 * I * D / sec / 1e12, 1)}
