@@ -257,6 +257,20 @@ def edge_cases(mods):
         with torch.no_grad():
             lg = model(input_ids=hole, attention_mask=hmask2, return_dict=True).logits
         put("text_hole", input_ids=hole, attention_mask=hmask2, logits=lg)
+        # (8) beam search: the reference forwards num_beams / length_penalty / early_stopping / num_return_sequences to HF generate (:382-391).
+        #     (a) no eos: every beam runs to the length limit; (b) an eos id that the beams do produce (the third token of (a)'s best hypothesis of row 0):
+        #     hypotheses finish at different lengths, the length penalty ranks them; (c) 4 beams, early_stopping=True, two returned hypotheses per prompt
+        from transformers import GenerationConfig
+
+        def beams(**kw):
+            gen = GenerationConfig(do_sample=False, bos_token_id=1, pad_token_id=0, **kw)
+            with torch.no_grad():
+                return model.generate(input_ids=ids, pixel_values=px, attention_mask=mask, generation_config=gen).detach().to(torch.int64)
+        ba = beams(num_beams=3, max_new_tokens=6, eos_token_id=None)
+        eos_b = int(ba[0, 2])
+        bb = beams(num_beams=3, max_new_tokens=8, eos_token_id=eos_b)
+        bc = beams(num_beams=4, max_new_tokens=8, eos_token_id=eos_b, early_stopping=True, num_return_sequences=2, length_penalty=0.6)
+        put("beams", input_ids=ids, attention_mask=mask, a_generated=ba, b_generated=bb, c_generated=bc, eos=np.array([eos_b]))
     return out
 
 

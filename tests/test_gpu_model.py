@@ -307,6 +307,30 @@ def test_edge_masks_with_interior_zeros_forward_matches_reference(dtype, golden_
     _check_logits("text_hole", out.logits, e["logits"], dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_beam_search_matches_reference(dtype, golden_dir):
+    """generate(num_beams > 1) (round 4 raised; the reference forwards it to HF generate, modeling_visualcla.py:382-391): the reference's own outputs for
+    (a) 3 beams without an eos id, (b) 3 beams with an eos id the beams do produce (hypotheses finish early, the length penalty ranks them, the returned
+    row is filled with the eos id), (c) 4 beams, early_stopping=True, length_penalty 0.6, two returned hypotheses per prompt.  fp32 mode: the ids of the
+    fixture; bf16 mode: the same calls run (every decode step goes through the B * num_beams-row kernels, the cache rows are gathered between steps)
+    and return well-formed hypotheses."""
+    e = _edge(golden_dir, "beams")
+    cfg, m, px, ids, mask = _edge_model(dtype)
+    assert torch.equal(ids, e["input_ids"])
+    eos = int(e["eos"][0])
+    kw = dict(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), do_sample=False, pad_token_id=0)
+    a = m.generate(num_beams=3, max_new_tokens=6, eos_token_id=None, **kw).cpu()
+    b = m.generate(num_beams=3, max_new_tokens=8, eos_token_id=eos, **kw).cpu()
+    c = m.generate(num_beams=4, max_new_tokens=8, eos_token_id=eos, early_stopping=True, num_return_sequences=2, length_penalty=0.6, **kw).cpu()
+    assert a.shape == e["a_generated"].shape and c.shape[0] == 4
+    if dtype == torch.float32:
+        assert torch.equal(a, e["a_generated"]), (a, e["a_generated"])
+        assert torch.equal(b, e["b_generated"]), (b, e["b_generated"])
+        assert torch.equal(c, e["c_generated"]), (c, e["c_generated"])
+    greedy = m.generate(max_new_tokens=6, eos_token_id=None, **kw).cpu()
+    assert greedy.shape == (2, 6)                              # num_beams = 1 is untouched by the beam path
+
+
 def test_masks_with_interior_zeros_are_refused_by_generate_only():
     """image_at_head=True + a left-padded text mask = [1]*Q ++ [0..0, 1..1] (modeling_visualcla.py:372-377): in `generate` the transformers
     versions the reference pins derive cumsum(mask) positions, which zeros between visible tokens would make differ from the absolute
@@ -386,8 +410,10 @@ def test_prefix_allowed_tokens_fn_constrains_generation():
     assert torch.equal(got, want)
     free = m.generate(**kw).cpu()
     assert torch.equal(free, O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=5))
-    with pytest.raises(ValueError):
-        m.generate(num_beams=2, **kw)
+    with pytest.raises(ValueError, match="do_sample=False"):          # beam SAMPLING is refused; beam search itself: test_edge_beam_search_matches_reference
+        m.generate(num_beams=2, **dict(kw, do_sample=True))
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        m.generate(num_return_sequences=2, **kw)
 
 
 def test_state_dict_roundtrip_and_dtype_switch():

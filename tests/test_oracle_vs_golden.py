@@ -224,3 +224,52 @@ def test_fp16_checkpoint_rerounding_is_quantified():
     assert ref16[1] < w_only[1] < ours[1]
     assert ours[1] <= 5e-3 and ours[0] <= 3e-2                     # logit std 0.32: < 2 % of the spread on average
     assert abs(ours[1] - direct[1]) <= 0.3 * ours[1]               # bf16(fp16(w)) vs bf16(w): the same distance
+
+
+def _oracle_beam_generate(cfg, W, px, ids, mask, **kw):
+    """visualcla.beam_search (the product's host-side beam bookkeeping) driven by the ORACLE's arithmetic: prefill of the expanded batch, then
+    one-token forwards on a K / V cache whose rows are re-ordered to the surviving beams -- the CPU stand-in for what VisualCLAModel.generate
+    does with libvisualcla_hip.so (tests/test_gpu_model.py::test_edge_beam_search_matches_reference replays the same fixture on the GPU)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visual-chinese-llama-alpaca_amd"))
+    from visualcla.beam_search import beam_search
+    nb = kw["num_beams"]
+    B, T = ids.shape
+    img = O.image_embeds(px, W, cfg)
+    x = O.embed_and_splice(ids, img, W, cfg).repeat_interleave(nb, dim=0)
+    m = mask.repeat_interleave(nb, dim=0)
+    cache = [None] * cfg.text.num_hidden_layers
+    h = O.llama_forward(x, W, cfg.text, m, cache, 0)
+    first = O.lm_head(h[:, -1:], W)[:, 0]
+    state = {"past": T, "mask": m}
+
+    def step(tokens, rows):
+        for i, (k, v) in enumerate(cache):
+            cache[i] = (k.index_select(0, rows), v.index_select(0, rows))
+        e = W["text_model.model.embed_tokens.weight"][tokens][:, None, :]
+        state["mask"] = torch.cat([state["mask"], torch.ones(B * nb, 1, dtype=m.dtype)], dim=1)
+        hh = O.llama_forward(e, W, cfg.text, state["mask"], cache, state["past"])
+        state["past"] += 1
+        return O.lm_head(hh, W)[:, 0]
+    return beam_search(first, step, B, nb, kw["max_new_tokens"], eos_ids=kw.get("eos_ids", ()), pad_token_id=0,
+                       length_penalty=kw.get("length_penalty", 1.0), early_stopping=kw.get("early_stopping", False),
+                       num_return_sequences=kw.get("num_return_sequences", 1))
+
+
+def test_edge_beam_search(golden_dir):
+    """num_beams > 1 (the reference forwards it to HF generate, modeling_visualcla.py:382-391): the host-side beam bookkeeping of this package
+    against the reference's own outputs -- (a) no eos, (b) hypotheses that finish early on an eos id and are ranked by the length penalty (the
+    returned row is filled with the eos id: HF treats pad_token_id = 0 as "unset"), (c) 4 beams, early_stopping=True, two returned hypotheses"""
+    e = _edge(golden_dir, "beams")
+    cfg, W, px, ids, mask = _tiny_inputs()
+    assert torch.equal(ids, e["input_ids"])
+    eos = int(e["eos"][0])
+    a = _oracle_beam_generate(cfg, W, px, ids, mask, num_beams=3, max_new_tokens=6)
+    assert torch.equal(a, e["a_generated"]), (a, e["a_generated"])
+    b = _oracle_beam_generate(cfg, W, px, ids, mask, num_beams=3, max_new_tokens=8, eos_ids=(eos,))
+    assert torch.equal(b, e["b_generated"]), (b, e["b_generated"])
+    c = _oracle_beam_generate(cfg, W, px, ids, mask, num_beams=4, max_new_tokens=8, eos_ids=(eos,), early_stopping=True, num_return_sequences=2,
+                              length_penalty=0.6)
+    assert torch.equal(c, e["c_generated"]), (c, e["c_generated"])
+    greedy = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=6)
+    assert not torch.equal(greedy, a)                         # the beams really found something else than the greedy path

@@ -722,8 +722,12 @@ class VisualCLAModel:
         stopping criteria (streaming), `prefix_allowed_tokens_fn` or top_k = 0 take the host-driven path (HF processors +
         torch.multinomial)."""
         gc = self._resolve_generation_config(generation_config, kwargs)
-        if (gc.num_beams or 1) != 1 or (gc.num_return_sequences or 1) != 1:
-            raise ValueError("only num_beams=1, num_return_sequences=1 is supported")
+        nb = int(gc.num_beams or 1)
+        if nb > 1 and gc.do_sample:
+            raise ValueError("beam search is implemented for do_sample=False (beam SAMPLING draws without replacement from an implementation-defined "
+                             "stream upstream); pass do_sample=False with num_beams > 1")
+        if nb == 1 and (gc.num_return_sequences or 1) != 1:
+            raise ValueError("num_return_sequences > 1 needs num_beams >= num_return_sequences")
         if prefix_allowed_tokens_fn is not None:
             # the reference forwards it to HF generate (modeling_visualcla.py:382-391), which turns it into this processor; it sees the
             # NEW tokens only, as every processor does when HF is driven by inputs_embeds.  Host-driven step path.
@@ -750,6 +754,43 @@ class VisualCLAModel:
             cur_stream.wait_stream(side)
         return toks
 
+    def _beam_generate(self, gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria):
+        """num_beams > 1 (the reference forwards it to HF generate, modeling_visualcla.py:382-391).  As HF does with `inputs_embeds`, every prompt's
+        spliced embeddings are repeated num_beams times AFTER the vision stack ran once per image; the prefill and every decode step run on the
+        B * num_beams rows through the same kernels as any batch of that size (host-driven steps), the K / V cache rows are re-ordered to the
+        surviving beams between steps (a row gather on the cache tensor: data movement, like HF's `reorder_cache`), and the beam bookkeeping is
+        visualcla/beam_search.py.  Returns [B * num_return_sequences, n] new tokens."""
+        from .beam_search import beam_search
+        lib = _lib.load()
+        t = self.config.text_config
+        nb = int(gc.num_beams)
+        B = embeds.shape[0]
+        rows = B * nb
+        x = embeds.repeat_interleave(nb, dim=0).contiguous()
+        cache = self._new_cache(rows, ctx_max)
+        key_mask = self._key_mask(None if am is None else am.repeat_interleave(nb, dim=0), rows, T, ctx_max)
+        first = self._prefill(x, cache, key_mask, all_logits=False)
+        ws = self._buf("llama", lib.vcla_llama_workspace_bytes(self._ctx, rows, 1))
+        step_logits = torch.empty(rows, t["vocab_size"], dtype=torch.float32, device=self._device)
+        ident = torch.arange(rows, device=self._device)
+        state = {"pos": T}
+
+        def step(tokens, beam_rows):
+            pos = state["pos"]
+            if not torch.equal(beam_rows, ident):        # the filled prefix of every cache row follows its beam
+                filled = cache.kv[:, :, :, :, :pos, :]
+                filled.copy_(filled.index_select(2, beam_rows))
+            with torch.cuda.device(self._device):
+                _lib.check(lib.vcla_llama_decode_step(self._ctx, tokens.contiguous().data_ptr(), rows, pos, None, 0, cache.kv.data_ptr(), ctx_max,
+                                                      _lib.ptr(key_mask), step_logits.data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            state["pos"] = pos + 1
+            return step_logits
+        procs = self._processors(gc, logits_processor)       # repetition penalty / no-repeat-ngram / min-new-tokens / caller's processors, on log-probs as HF
+        return beam_search(first, step, B, nb, n_new, eos_ids=eos, pad_token_id=gc.pad_token_id, length_penalty=float(gc.length_penalty if gc.length_penalty is not None else 1.0),
+                           early_stopping=gc.early_stopping if gc.early_stopping is not None else False,
+                           num_return_sequences=int(gc.num_return_sequences or 1), processors=procs,
+                           stopping_criteria=list(stopping_criteria) if stopping_criteria else ())
+
     def _generate_on_stream(self, gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph, device_sampling):
         lib = _lib.load()
         t = self.config.text_config
@@ -769,11 +810,13 @@ class VisualCLAModel:
         if n_new <= 0:
             raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
         ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
+        eos = self._eos_list(gc)
+        if int(gc.num_beams or 1) > 1:
+            return self._beam_generate(gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria)
         cache = self._new_cache(B, ctx_max, _persistent=persistent)
         key_mask = self._key_mask(am, B, T, ctx_max)
         logits = self._prefill(embeds, cache, key_mask, all_logits=False, _persistent=persistent)
 
-        eos = self._eos_list(gc)
         pad_id = gc.pad_token_id if gc.pad_token_id is not None else (eos[0] if eos else 0)
         procs = self._processors(gc, logits_processor)
         criteria = list(stopping_criteria) if stopping_criteria else []
