@@ -3,10 +3,14 @@
 
 One "step" = one pass of the hot path over one batch of synthetic requests:
     ViT-L/14 (224 px) -> Resampler -> projection -> splice -> LLaMA-7B prefill (T=128) -> 128-token greedy decode.
-Two workloads are timed per run (SURVEY.md section 8d "two regimes, report both"):
+Four workloads are timed per default run (SURVEY.md section 8d "two regimes, report both"; every leg carries BOTH images/sec definitions:
+`images_per_sec` = whole requests, `images_per_sec_prefill` = images through ViT + Resampler + projection + prefill):
   * configs[1] -- `value`: B = 1 request per GPU (BASELINE.json configs[1]; the latency / HBM-bound regime), EXACTLY --steps steps;
   * configs[2] -- `images_per_sec`, `config2`: B = 64 requests per GPU (BASELINE.json configs[2]; ViT + Resampler throughput,
-    the MFMA-bound vision / prefill regime next to batch decode), a few steps of its own (--steps-b64).
+    the MFMA-bound vision / prefill regime next to batch decode), a few steps of its own (--steps-b64);
+  * configs[4]'s per-GPU share -- `config4`: fp8 weights, 336 px, B = 32 = 256 / 8, in both numeric modes (--steps-c4);
+  * `strong256` -- north_star's scaling workload: a GLOBAL batch of 256 (bf16, 224 px) split over the ranks, B = 256 / N per GPU
+    (--steps-strong): a driver series --gpus 1 / 2 / 4 / 8 reads ">= 6x images/sec at batch 256" off this leg.
 Weights are random-init of the 7B architecture, inputs synthetic and resident in HBM before the timed
 region.
 
