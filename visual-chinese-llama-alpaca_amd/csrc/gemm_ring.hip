@@ -14,7 +14,7 @@
 //   * stage = KS K-slabs of 64: BM x 64 activations + BN x 64 weights, `global_load_lds_dwordx4` pieces of 1 KiB (8 rows x 128 B; fp8 weights:
 //     16 rows x 64 B) dealt round-robin to the 8 waves, bank-conflict swizzle applied on the SOURCE address (as gemm_mfma256.hip);
 //   * NS stages: NS - 1 in flight while one is consumed; all DMA from inline asm with hand-counted vmcnt, ONE barrier per stage; every wave
-//     issues exactly PP DMA instructions per stage (absent pieces and the K tail are 4-byte dummies into a sink) so the count is a literal;
+//     issues exactly PP DMA instructions per stage, branch-free (absent pieces and the K tail land in a 1-KiB sink), so the count is a literal;
 //   * fp8 (e4m3fn) weights (W8A16, BASELINE configs[4]): the 1-byte rows travel as they are (half the HBM and DMA bytes), are widened to bf16 ONCE per
 //     stage by the workgroup (exact) into the image the fragment reads use, and the per-row scale is applied in the epilogue -- the same function of
 //     the dequantised weights as the M <= 128 decode kernels compute.
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
     tile_assign(blockIdx.x, tiles_m, tiles_n, tiles_m, tm, tn);      // consecutive blocks of an XCD: the row tiles of ONE column tile (they share its W rows)
     const int m0 = tm * BM, n0 = tn * BN;
     const unsigned lds_u = (unsigned)(uintptr_t)(lds_ptr_t)ring;
-    const unsigned sink = lds_u + SINK;                         // 256 B nobody reads: destination of the dummies
+    const unsigned sink = lds_u + SINK;                         // 1 KiB nobody reads: destination of the absent / out-of-range pieces
 
     // ---- sources of this wave's pieces (slab 0), LDS offsets inside a slab.  Row-major operands: rows lda / K elements apart, K slabs 128 B
     // (fp8: 64 B) apart; slab-major operands ([K/64][rows][64], vcla_gemm_args.A_slab / W_slab / W_q8_slab): rows 128 B apart, slabs rows * 128 B
@@ -124,24 +124,23 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         }
     }
     const int nslab = a.K / GM_BK;
-    // issue group j = {activations of stage j, weights of stage j + WLEAD}: PP instructions, always (absent pieces, stages outside [0, nst): 4-byte
-    // dummies into the sink).  buf_a / buf_w: the ring buffers the two stages go to.
+    // issue group j = {activations of stage j, weights of stage j + WLEAD}: PP instructions, always, and BRANCH-FREE: a piece that is absent (waves past the
+    // last weight piece) or lies outside [0, nslab) is still one 1-KiB DMA -- of a valid address (slab 0 of the wave's own piece) into the SINK.  (The first
+    // form branched around 4-byte dummies: ~170 scalar instructions per K slab in the 64 x 64 tile against ~75 now.  Measured EQUAL -- o_proj 23.7 vs 24.3 us,
+    // down_proj 55.8 vs 58.1 -- as were 9 single-slab stages against 4 double-slab ones (128 vs 96 KiB in flight) and slab-major operands: the 64 x 64 tile
+    // sits at ~20 B/clk/CU whichever of issue overhead, ring depth or access shape is relieved ALONE, profiles/r05_ring_microbench.txt.)  buf_a / buf_w: the
+    // ring buffers of the two stages.
     auto issue = [&](int j, int buf_a, int buf_w) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int slab_a = j * KS + k, slab_w = (j + WLEAD) * KS + k;
             const bool live_a = j >= 0 && slab_a < nslab, live_w = slab_w < nslab;
+            const int64_t oa = live_a ? (int64_t)slab_a * a_ss : 0, ow = live_w ? (int64_t)slab_w * w_ss : 0;
             const unsigned ab = lds_u + buf_a * A_STAGE + k * A_BYTES, wb = lds_u + W_RING + buf_w * W_STAGE + k * W_BYTES;
 #pragma unroll
-            for (int i = 0; i < IA; ++i) {
-                if (live_a) gr_dma16(asrc[i] + (int64_t)slab_a * a_ss, ab + (unsigned)(wave + 8 * i) * 1024u);
-                else gr_dma4(asrc[i], sink);
-            }
+            for (int i = 0; i < IA; ++i) gr_dma16(asrc[i] + oa, live_a ? ab + (unsigned)(wave + 8 * i) * 1024u : sink);
 #pragma unroll
-            for (int i = 0; i < IW; ++i) {
-                if (live_w && wreal[i]) gr_dma16(wsrc[i] + (int64_t)slab_w * w_ss, wb + (unsigned)(wave + 8 * i) * 1024u);
-                else gr_dma4(wsrc[i], sink);
-            }
+            for (int i = 0; i < IW; ++i) gr_dma16(wsrc[i] + ow, (live_w && wreal[i]) ? wb + (unsigned)(wave + 8 * i) * 1024u : sink);
         }
     };
     // W8: widen this wave's share of the e4m3 weights in W-ring buffer `buf_w` into bf16 image `img` (unit u = 16 bytes = 16 weights of one row:
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
 // ------------------------------------------------------------------ host side
 template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
 static int launch_ring_cfg(const vcla_gemm_args* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)NS * KS * BM * 128 + (size_t)(NS + (W8 ? 1 : 0)) * KS * (W8 ? BN * 64 : BN * 128) + (W8 ? (size_t)2 * KS * BN * 128 : 0) + 256;
+    constexpr size_t lds = (size_t)NS * KS * BM * 128 + (size_t)(NS + (W8 ? 1 : 0)) * KS * (W8 ? BN * 64 : BN * 128) + (W8 ? (size_t)2 * KS * BN * 128 : 0) + 1024;
     static_assert(lds <= 160 * 1024, "ring exceeds the 160 KiB of a CU");
     auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
@@ -259,6 +258,10 @@ static int launch_ring(const vcla_gemm_args* a, hipStream_t s) {
     if constexpr (EPI == VCLA_EPI_SWIGLU) return vcla_fail(VCLA_ERR_BAD_ARG, "gemm: the SwiGLU ring tile is 256 x 96");
     else {
         if (cfg == 2) return launch_ring_cfg<EPI, OutT, 128, 96, 4, 2, 5, 1, W8>(a, s);
+        if constexpr (!W8) {      // bf16 weights: 9 single-slab stages (128 KiB in flight) instead of 4 double-slab ones (96 KiB): measured equal (+2 %); VCLA_RING_C3=0: the first form
+            static const int c3_env = getenv("VCLA_RING_C3") ? atoi(getenv("VCLA_RING_C3")) : 1;
+            if (c3_env) return launch_ring_cfg<EPI, OutT, 64, 64, 4, 2, 9, 1, W8>(a, s);
+        }
         return launch_ring_cfg<EPI, OutT, 64, 64, 4, 2, 4, 2, W8>(a, s);
     }
 }
