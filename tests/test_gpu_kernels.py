@@ -292,6 +292,23 @@ def test_gemm_ring_slab_major_operands(lib, M, N, K, epi, fk, fp8):
     assert torch.equal(got, base) and torch.equal(mixed, base)
 
 
+@pytest.mark.parametrize("M,N,K,epi,fk", [(256, 4096, 4096, 0, 11), (256, 22016, 4096, 3, 11), (200, 12288, 4096, 0, 11), (255, 4096, 11008, 0, 11), (131, 1024, 128, 3, 12),
+                                          (250, 384, 704, 0, 13), (144, 128, 4096, 0, 14), (130, 256, 192, 0, 11)])
+def test_gemm_ring_fragment_major_weights(lib, M, N, K, epi, fk):
+    """the ring kernel with the weight pieces taken from the fragment-major twin (W_frag: one contiguous KiB per 16 x 32 fragment, lane-ordered in LDS):
+    bit-identical to the row-major pieces (same fragments, same MFMA order), every tile, ragged M"""
+    from visualcla.weights import to_fragment_major
+    g = torch.Generator().manual_seed(M + N + K + epi + 1)
+    a = bf16r(torch.randn(M, K, generator=g)).to(DEV, torch.bfloat16)
+    wp = _pack(bf16r(torch.randn(N, K, generator=g) * 0.05))
+    n_out = N // 2 if epi == 3 else N
+    res = bf16r(torch.randn(M, n_out, generator=g)).to(DEV, torch.bfloat16)
+    import os as _os
+    base = lib.gemm(a, wp, N, residual=res, epilogue=epi, force_kernel=fk)
+    got = lib.gemm(a, wp, N, residual=res, epilogue=epi, force_kernel=fk, w_frag=to_fragment_major(wp))
+    assert torch.equal(got, base)
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "gemv"])
 def test_gemm_f32_output_and_identity(lib, kernel):
     """A = I (asymmetric W) catches operand/row-column swaps; fp32 output keeps the full accumulator."""

@@ -1148,8 +1148,8 @@ def test_7b_batch_rows_match_oracle(model_7b, B, rows):
     end against the ORACLE: the prefill's last-position logits and two teacher-forced decode steps of three rows of a B-row
     generate().  Rows are independent (no cross-sample reduction on the path), so the oracle runs on those rows only; the HIP side
     runs the full-batch instances the benchmark times -- B = 64: 256x256 prefill tiles, streaming decode GEMMs with MT = 4, the 2-wave
-    batch decode attention; B = 256: the decode steps on the 128-row MFMA tiles (K slices + fused reduce / RMSNorm for o_proj and
-    down_proj, two K slices for qkv) and the batch decode attention over 8192 (sequence, head) pairs."""
+    batch decode attention; B = 256: the decode steps on the ring kernel (gemm_ring.hip: one launch per GEMM, whole K per tile, the weight pieces from
+    the fragment-major twins) and the batch decode attention over 8192 (sequence, head) pairs."""
     from transformers import LogitsProcessorList
     m, ocfg = model_7b
     _oracle_threads()

@@ -222,6 +222,29 @@ def main():
                 del w_sls, q_sls
                 del ws, q8s
             print(f"ring  M={M:3d} layer sums (qkv + o + gate/up + down): " + "  ".join(f"k{fk}{'/fp8' if f8 else ''}{'/slab' if sl else ''}={v*1e6:.0f}us" for (fk, f8, sl), v in tot.items() if fk in (1, 11)))
+    if "ringwf" in which:
+        print("== ring kernel (k11 / k14), bf16: weight pieces from the row-major matrix (8-row gathers) vs from the fragment-major twin (1 KiB contiguous), hipGraph replay over 8 matrices")
+        from visualcla.weights import to_fragment_major
+        for M in [int(x) for x in os.environ.get("VCLA_BENCH_MS", "256,192,129").split(",")]:
+            tot = {}
+            for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
+                a = rnd(M, K)
+                ws = [packw(N, K) for _ in range(8)]
+                wfs = [to_fragment_major(w) for w in ws]
+                n_out = N // 2 if epi == 3 else N
+                out = torch.empty(M, n_out, dtype=torch.bfloat16, device=DEV)
+                res = rnd(M, n_out) if tag in ("o", "down") else None
+                for fk, frag in [(f, fr) for f in (11, 12, 13, 14) for fr in (False, True)]:
+                    if fk > 12 and epi == 3:
+                        continue
+                    def run():
+                        for w, wf in zip(ws, wfs):
+                            _lib.gemm(a, w, N, epilogue=epi, out=out, residual=res, force_kernel=fk, w_frag=wf if frag else None)
+                    t = timeit_graph(run, reps=10) / len(ws)
+                    print(f"ringwf M={M:3d} {tag:8s} k{fk} {'fragment-major' if frag else 'row-major     '} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {N*K*2/t/1e9:7.1f} GB/s of W")
+                    tot[(fk, frag)] = tot.get((fk, frag), 0.0) + t
+                del ws, wfs
+            print(f"ringwf M={M:3d} layer sums: " + "  ".join(f"k{fk}{'/frag' if fr else ''}={v*1e6:.0f}us" for (fk, fr), v in tot.items() if fk == 11))
     if "slab256" in which:
         print("== 256 x 256 direct-to-LDS kernel (k4): row-major operands (8-row x 128-byte DMA pieces) vs slab-major A / W (1 KiB contiguous pieces), hipGraph replay")
         from visualcla.weights import to_slab_major

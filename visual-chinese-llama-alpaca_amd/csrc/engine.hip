@@ -484,6 +484,11 @@ static int gemm(vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const 
         a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 11;
         return vcla_gemm(&a, ctx->c.act_dtype, s);
     }
+    if (wv && M > 128 && M <= 256 && wv->frag && ctx->c.act_dtype == VCLA_BF16 && !out_f32) {
+        // 129 - 256 rows (ring kernel): the fragment-major twin makes the weight half of every stage contiguous 1-KiB DMA pieces
+        a.W_frag = wv->frag;
+        return vcla_gemm(&a, ctx->c.act_dtype, s);
+    }
     if (wv && M <= 128 && ctx->c.act_dtype == VCLA_BF16) {   // decode-side weight copies (prefill tiles read the bf16 row-major W)
         // fp8 copies (when loaded) serve the DECODE steps only (ctx->run.decode_step; a short prefill keeps the bf16 values): half the HBM
         // bytes.  M = 1 GEMV: 1.3x end to end; panel kernel: 112 vs 132 us per layer at

@@ -57,8 +57,12 @@ __device__ __forceinline__ bf16x8_t gr_fp8x8_to_bf16x8(uint32_t lo, uint32_t hi)
 // barrier (-0 .. 7 %, inside the noise in the model), nt policy on the weight pieces (equal); with the fragment reads and MFMAs REMOVED the kernel
 // is 3 % faster, without the weight DMA 12 %, without the activation DMA 0 %: the stage cadence is set by the round trip of NS - 1 stages in flight
 // (~90 - 130 KiB per CU against ~2 us under load), not by issue, compute or either operand alone.
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
+// WF (bf16 weights): the weight pieces come from the FRAGMENT-major twin (vcla_gemm_args.W_frag, [N_pad/16][K/32][64 lanes][8]: what the M <= 128 decode kernels
+// stream; the LLaMA matrices carry it already) -- piece = one (16 rows x 32 k) MFMA fragment = 1 KiB CONTIGUOUS in global memory, landing in LDS in lane order, so
+// the fragment read is lane * 16 (conflict-free, no swizzle).  Half of a stage's DMA instructions are then contiguous KiBs instead of 8-row gathers.
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, bool WF = false>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int tiles_m, int tiles_n, int n_pad) {
+    static_assert(!(W8 && WF), "fragment-major pieces are the bf16 twin");
     static_assert(WM * WN == 8 && BM % 64 == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NS >= 3, "tile / wave grid");
     static_assert(EPI != VCLA_EPI_SWIGLU || (BN / WN) % 32 == 0, "SwiGLU pairs (gate, up) tiles inside a wave");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
     const int64_t a_rs = a.A_slab ? 128 : a.lda * 2, a_ss = a.A_slab ? a.a_slab_rows * 128 : 128;
     constexpr int W_ROW = W8 ? 64 : 128;                      // bytes of one weight row inside a K slab
     const bool wslab = W8 ? a.W_q8_slab != nullptr : a.W_slab != nullptr;
-    const char* Wb = (const char*)(W8 ? (wslab ? a.W_q8_slab : a.W_q8) : (wslab ? a.W_slab : a.W));
-    const int64_t w_rs = wslab ? W_ROW : (int64_t)a.K * (W8 ? 1 : 2), w_ss = wslab ? (int64_t)n_pad * W_ROW : W_ROW;
+    const char* Wb = (const char*)(WF ? a.W_frag : (W8 ? (wslab ? a.W_q8_slab : a.W_q8) : (wslab ? a.W_slab : a.W)));
+    const int64_t w_rs = wslab ? W_ROW : (int64_t)a.K * (W8 ? 1 : 2), w_ss = WF ? 2048 : (wslab ? (int64_t)n_pad * W_ROW : W_ROW);
     const char* asrc[IA];
     const char* wsrc[IW];
     bool wreal[IW];
@@ -110,7 +114,11 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
         const int q = wave + 8 * i;
         wreal[i] = q < PW;
         const int qq = wreal[i] ? q : 0;
-        if constexpr (W8) {
+        if constexpr (WF) {
+            int t16 = n0 / 16 + (qq >> 1);                        // piece qq = fragment (16-row tile qq / 2, k-step qq % 2) of the slab
+            t16 = t16 < n_pad / 16 ? t16 : n_pad / 16 - 1;
+            wsrc[i] = Wb + ((int64_t)t16 * (a.K / 32) + (qq & 1)) * 1024 + lane * 16;
+        } else if constexpr (W8) {
             const int row = qq * 16 + (lane >> 2);                // 16 rows x 64 B per piece, stored LINEAR (the widening pass reads 16 B per lane in order)
             int wr = n0 + row;
             wr = wr < n_pad ? wr : n_pad - 1;
@@ -203,7 +211,10 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t wf[NJ], af[MI];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * (BN / WN) + j * 16 + frow, kk * 4 + fch));
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (WF) wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + ((wn * (BN / WN) / 16 + j) * 2 + kk) * 1024 + lane * 16);
+                    else wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + lds_off(wn * (BN / WN) + j * 16 + frow, kk * 4 + fch));
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm * (BM / WM) + i * 16 + frow, kk * 4 + fch));
 #pragma unroll
@@ -220,11 +231,15 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(vcla_gemm_args a, int ti
 }
 
 // ------------------------------------------------------------------ host side
-template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8>
+template <int EPI, typename OutT, int BM, int BN, int WM, int WN, int NS, int KS, bool W8, bool WF = false>
 static int launch_ring_cfg(const vcla_gemm_args* a, hipStream_t s) {
+    if constexpr (!W8 && !WF && sizeof(OutT) == 2) {          // bf16 output, bf16 weights with a fragment-major twin: its pieces are contiguous KiBs (VCLA_RING_WF=0: row-major pieces)
+        static const int wf_env = getenv("VCLA_RING_WF") ? atoi(getenv("VCLA_RING_WF")) : 1;
+        if (wf_env && a->W_frag && !a->W_slab) return launch_ring_cfg<EPI, OutT, BM, BN, WM, WN, NS, KS, false, true>(a, s);
+    }
     constexpr size_t lds = (size_t)NS * KS * BM * 128 + (size_t)(NS + (W8 ? 1 : 0)) * KS * (W8 ? BN * 64 : BN * 128) + (W8 ? (size_t)2 * KS * BN * 128 : 0) + 1024;
     static_assert(lds <= 160 * 1024, "ring exceeds the 160 KiB of a CU");
-    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8>;
+    auto kern = gemm_ring_kernel<EPI, OutT, BM, BN, WM, WN, NS, KS, W8, WF>;
     static bool attr_set[VCLA_MAX_DEVICES] = {};   // per instantiation and device
     { const int rc_ = vcla_raise_dyn_lds((const void*)kern, lds, attr_set); if (rc_) return rc_; }
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
