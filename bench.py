@@ -186,13 +186,14 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
     alg_bytes = 2 * I * D * 2
     if M > 64:
         # 65 - 128 decode rows: the split-K panel kernel; 129 - 256: the ring kernel (gemm_ring.hip).  The weights are streamed once per launch, so the
-        # bound quoted is HBM; at M = 256 neither HBM nor MFMA binds (46 GF and 180 MB in ~62 us = 0.74 PF/s and 2.9 TB/s) but what a CU can keep in
+        # bound quoted is HBM; at M = 256 neither HBM nor MFMA binds (46 GF and 180 MB in ~57 us = 0.8 PF/s and 3.2 TB/s) but what a CU can keep in
         # flight against the loaded round trip, DESIGN.md section 5 "Round 5"
         x = torch.randn(M, D, device=model.device).to(torch.bfloat16)
         out = torch.empty(M, I, dtype=torch.bfloat16, device=model.device)
         ws = torch.zeros(64 << 20, dtype=torch.uint8, device=model.device)
 
-        use_frag = M <= 128 and f"llama.l0.wgu.f" in P      # M <= 128 with the fragment-major copy: the split-K panel kernel; else the row-major MFMA tiles
+        # the fragment-major twin, as the engine passes it: M <= 128 -> the split-K panel kernel streams it; 129 - 256 -> the ring kernel takes its weight pieces from it
+        use_frag = f"llama.l0.wgu.f" in P
 
         def run_tiles():
             for l in range(L):
@@ -200,9 +201,10 @@ def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
                           w_frag=P[f"llama.l{l}.wgu.f"] if use_frag else None)
         sec = _event_time(run_tiles, n_rep) / L
         achieved = alg_bytes / sec / 1e9
-        return {"bound": "hbm", "kernel": (f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM on the fragment-major copy, bf16)" if use_frag else
-                                                 (f"gemm_ring_kernel<SWIGLU, 256x96> (B={M} gate/up decode GEMM: full-K tiles fed by an LDS-DMA ring, bf16; the default dispatch for 129 - 256 rows)"
-                                                  if M > 128 else f"vcla_gemm default dispatch on the row-major weights (B={M} gate/up decode GEMM, bf16)")),
+        return {"bound": "hbm", "kernel": (f"gemm_ring_kernel<SWIGLU, 256x96> (B={M} gate/up decode GEMM: full-K tiles fed by an LDS-DMA ring, weight pieces from the "
+                                                 f"{'fragment-major twin' if use_frag else 'row-major matrix'}, bf16; the default dispatch for 129 - 256 rows)" if M > 128 else
+                                                 (f"gemm_panel_kernel<SWIGLU> (B={M} gate/up split-K panel GEMM on the fragment-major copy, bf16)" if use_frag else
+                                                  f"vcla_gemm default dispatch on the row-major weights (B={M} gate/up decode GEMM, bf16)")),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": n_rep * L, "mfma_tflops": round(2.0 * M * 2 * I * D / sec / 1e12, 1)}
