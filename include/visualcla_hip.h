@@ -126,8 +126,9 @@ typedef struct vcla_gemm_args {
                                the FULL K, no split-K partials, no LDS in the main loop);
                              10 fp8 MFMA 256x256x128 direct-to-LDS (needs A_q8 + a_scale + W_q8 + w_scale);
                              11 ring MFMA (the default for 129 <= M <= 256: full-K tiles fed by an LDS-DMA ring, row-major bf16 A, bf16 W or
-                               fp8 W_q8 + w_scale, epilogue NONE / SWIGLU; tile chosen per shape), 12 / 13 / 14 = the same with the
-                               256x96 / 128x96 / 64x64 tile forced */
+                               fp8 W_q8 + w_scale, epilogue NONE / SWIGLU; tile chosen per shape; with bf16 W, bf16 output and W_frag set the
+                               weight pieces come from the fragment-major twin: bit-identical, contiguous DMA), 12 / 13 / 14 = the same
+                               with the 256x96 / 128x96 / 64x64 tile forced */
     /* optional fused RMSNorm prologue (GEMV kernel, M <= 8 only): A holds the UN-normalised rows and the
        kernel computes gamma * x * rsqrt(mean(x^2) + eps) on the fly (LlamaRMSNorm + Linear in one launch) */
     const float* norm_gamma; /* [K] or NULL */
@@ -136,7 +137,8 @@ typedef struct vcla_gemm_args {
     void* splitk_ws;
     size_t splitk_ws_bytes;
     /* optional fragment-major twin of W, [N_pad/16][K/32][64 lanes][8] bf16 (visualcla/weights.py:to_fragment_major):
-       lets the M <= 128 panel kernel stream each 16-row tile as one contiguous region */
+       lets the M <= 128 panel kernel stream each 16-row tile as one contiguous region and the 129 - 256-row ring kernel DMA
+       its weight pieces as contiguous KiBs */
     const void* W_frag;
     /* optional OCP fp8 (e4m3fn) weight copies for the HBM-bound decode kernels, per-row fp32 scale w_scale [N_pad]
        (W ~= q * w_scale[row]); W_q8: [N_pad, K] row-major (M = 1 GEMV); W_q8_frag: [N_pad/16][K/64][64 lanes][16]
