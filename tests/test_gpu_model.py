@@ -416,6 +416,50 @@ def test_prefix_allowed_tokens_fn_constrains_generation():
         m.generate(num_return_sequences=2, **kw)
 
 
+def test_generation_config_fields_reach_the_decode_loop_or_are_refused():
+    """the reference forwards its whole generation config to HF generate (modeling_visualcla.py:382-391): the length rules of the `inputs_embeds`
+    case, config-selected processors outside the device sampler's set (host-driven steps, transformers' classes in transformers' order:
+    tests/test_host_cpu.py::test_logits_processors_equal_transformers_on_random_configs), `min_length` on the device-resident loop, and the
+    refusal BY NAME of what is not implemented"""
+    from transformers.generation.logits_process import NoBadWordsLogitsProcessor
+    cfg = O.cfg_tiny()
+    W = O.make_weights(cfg, seed=0)
+    px, ids, mask = O.make_inputs(cfg, 2, 24)
+    m = make_hip_model(cfg, W, torch.float32)
+    base = dict(input_ids=ids.cuda(), pixel_values=px.cuda(), attention_mask=mask.cuda(), do_sample=False, eos_token_id=None)
+    want = O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=6)
+    T = ids.shape[1]
+    # an explicit max_length counts the prompt; with nothing left HF raises
+    assert torch.equal(m.generate(max_length=T + 6, **base).cpu(), want)
+    assert torch.equal(m.generate(max_length=T + 6, max_new_tokens=3, **base).cpu(), want[:, :3])
+    with pytest.raises(ValueError, match="max_length"):
+        m.generate(max_length=T, **base)
+    # bad_words_ids: the greedy path's own first tokens are banned -> the config field and the same processor passed by hand agree, the ids are gone
+    banned = [[int(t)] for t in want[:, 0].unique()]
+    got = m.generate(max_new_tokens=6, bad_words_ids=banned, **base).cpu()
+    by_hand = m.generate(max_new_tokens=6, logits_processor=[NoBadWordsLogitsProcessor(banned, None)], **base).cpu()
+    flat = torch.tensor([b[0] for b in banned])
+    assert torch.equal(got, by_hand) and not bool(torch.isin(got, flat).any()) and not torch.equal(got, want)
+    assert torch.equal(got, O.visualcla_generate(ids, px, mask, W, cfg, max_new_tokens=6,
+                                                 select_fn=lambda lg, gen: lg.index_fill(1, flat, float("-inf")).argmax(-1)))
+    # suppress_tokens likewise; forced_eos_token_id puts the eos id at the last position of the budget
+    sup = m.generate(max_new_tokens=4, suppress_tokens=[int(t) for t in flat], **base).cpu()
+    assert torch.equal(sup, got[:, :4])
+    eos = int(want[0, 5]) if int(want[0, 5]) not in want[0, :5].tolist() else 3
+    forced = m.generate(max_new_tokens=4, forced_eos_token_id=eos, **dict(base, eos_token_id=eos, pad_token_id=0)).cpu()
+    assert forced.shape[1] <= 4 and bool(((forced == eos).sum(dim=1) >= 1).all())
+    # min_length (less the prompt) masks the eos id on the device-resident loop exactly as min_new_tokens does
+    stop = int(want[0, 1])
+    a = m.generate(max_new_tokens=6, min_length=T + 4, **dict(base, eos_token_id=stop, pad_token_id=0)).cpu()
+    b = m.generate(max_new_tokens=6, min_new_tokens=4, **dict(base, eos_token_id=stop, pad_token_id=0)).cpu()
+    assert torch.equal(a, b) and not bool((a[:, :4] == stop).any())
+    # refused by name, never dropped
+    for kw, word in ((dict(return_dict_in_generate=True), "return_dict_in_generate"), (dict(penalty_alpha=0.5, top_k=4), "penalty_alpha"),
+                     (dict(guidance_scale=2.0), "guidance_scale"), (dict(streamer=object()), "streamer"), (dict(max_new_token=3), "max_new_token")):
+        with pytest.raises(ValueError, match=word):
+            m.generate(**dict(base, max_new_tokens=2, **kw))
+
+
 def test_state_dict_roundtrip_and_dtype_switch():
     cfg = O.cfg_tiny()
     W = O.make_weights(cfg, seed=0)

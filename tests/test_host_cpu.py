@@ -465,3 +465,185 @@ def test_check_request_validates_in_one_pass_on_cpu():
     am = m._check_request(txt, tm, Q, for_generate=False)[1]
     assert am.shape == (2, Q + 10) and bool(am[:, :Q].all()) and am[1, Q:Q + 2].tolist() == [0, 0]
     assert m._check_request(txt, tm, 0, for_generate=False)[1] is not None                 # text-only (no image): plain left padding is fine
+
+
+def test_beam_search_bookkeeping_equals_transformers_on_random_configs():
+    """visualcla.beam_search (host bookkeeping of generate(num_beams > 1)) against transformers' own beam search -- what the reference's generate() forwards
+    to (models/visualcla/modeling_visualcla.py:382-391) -- on a tiny random LLaMA driven by `inputs_embeds`: 80 random draws over batch, left padding, beams,
+    length limits, eos sets the model really produces (one, two, five ids), pad ids (unset / 0 / another), length penalties (incl. 0 and negative),
+    early_stopping in {False, True, "never"}, several returned hypotheses, repetition penalty and no-repeat-ngram processors.  Ids must be EQUAL.  The step
+    function here re-runs the full forward of the re-ordered sequences (no cache): the cache gather is covered by the golden-fixture tests."""
+    import random
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
+    from transformers import LlamaConfig, LlamaForCausalLM, LogitsProcessorList, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor
+    from visualcla.beam_search import beam_search
+    torch.manual_seed(0)
+    V, H = 23, 32
+    cfg = LlamaConfig(vocab_size=V, hidden_size=H, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      max_position_embeddings=64, pad_token_id=None, bos_token_id=None, eos_token_id=None)
+    m = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(6.0)                                    # sharper distributions: the beams diverge and the eos ids get produced
+
+    def ours(emb, mask, nb, L, eos, pad, lp, es, nrs, procs):
+        B = emb.shape[0]
+        x, mk = emb.repeat_interleave(nb, 0), mask.repeat_interleave(nb, 0)
+        state = {"seq": torch.zeros(B * nb, 0, dtype=torch.long)}
+
+        def fwd():
+            s = state["seq"]
+            e = torch.cat([x, m.get_input_embeddings()(s)], 1)
+            am = torch.cat([mk, torch.ones(B * nb, s.shape[1], dtype=mk.dtype)], 1)
+            return m(inputs_embeds=e, attention_mask=am, position_ids=(am.cumsum(-1) - 1).clamp(min=0)).logits[:, -1].float()
+
+        def step(tok, rows):
+            state["seq"] = torch.cat([state["seq"].index_select(0, rows), tok[:, None]], 1)
+            return fwd()
+        return beam_search(fwd(), step, B, nb, L, eos_ids=eos, pad_token_id=pad, length_penalty=lp, early_stopping=es, num_return_sequences=nrs, processors=procs)
+
+    rng = random.Random(1)
+    hit_eos = finished_early = 0
+    for case in range(80):
+        B, T, nb, L = rng.choice([1, 2, 3]), rng.choice([3, 5, 8]), rng.choice([2, 3, 4, 5]), rng.choice([1, 2, 4, 7, 10])
+        eos = rng.choice([(), (3,), (3, 7), (1, 2, 3, 4, 5)])
+        pad = rng.choice([None, 0, 9])
+        lp, es = rng.choice([1.0, 0.0, 0.6, 2.0, -1.0]), rng.choice([False, True, "never"])
+        nrs = rng.choice([1, 1, nb, max(1, nb - 1)])
+        rp, ng = rng.choice([None, None, 1.3]), rng.choice([None, None, 2])
+        emb = torch.randn(B, T, H, generator=torch.Generator().manual_seed(case))
+        mask = torch.ones(B, T, dtype=torch.long)
+        for b in range(B):
+            mask[b, :rng.choice([0, 0, 1, 2])] = 0
+        procs = LogitsProcessorList(([RepetitionPenaltyLogitsProcessor(rp)] if rp else []) + ([NoRepeatNGramLogitsProcessor(ng)] if ng else []))
+        kw = dict(num_beams=nb, max_new_tokens=L, do_sample=False, length_penalty=lp, early_stopping=es, num_return_sequences=nrs,
+                  eos_token_id=list(eos) if eos else None, pad_token_id=pad)
+        if rp:
+            kw["repetition_penalty"] = rp
+        if ng:
+            kw["no_repeat_ngram_size"] = ng
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = m.generate(inputs_embeds=emb, attention_mask=mask, **kw)
+            got = ours(emb, mask, nb, L, eos, pad, lp, es, nrs, procs)
+        assert ref.shape == got.shape and torch.equal(ref, got), (case, kw, ref, got)
+        hit_eos += int(bool(eos) and bool(torch.isin(ref, torch.tensor(list(eos) or [-5])).any()))
+        finished_early += int(ref.shape[1] < L)
+    assert hit_eos >= 10 and finished_early >= 5             # the draw really exercises finished hypotheses
+
+
+def test_logits_processors_equal_transformers_on_random_configs():
+    """visualcla.logits_processors (GenerationConfig -> processor list + token budget of one generate() call) against transformers' generate driven by
+    `inputs_embeds` -- what the reference's generate() forwards its config to (models/visualcla/modeling_visualcla.py:382-391).  A tiny random LLaMA runs HF's
+    generate with `output_scores`; the sequences it produced are replayed step by step through THIS package's processor list and the processed scores must be
+    the ones HF reported (same -inf pattern, values to 1e-4), for 70 random draws over: max_new_tokens / max_length (counts the prompt) / neither, eos sets,
+    min_new_tokens and min_length (less the prompt), repetition penalty, no-repeat-ngram, bad words, sequence bias, suppressed tokens (always / at the start),
+    forced bos / eos, exponential length decay, inf / nan removal, renormalisation, a caller's processor, prefix_allowed_tokens_fn, and when sampling:
+    temperature, top-k, top-p, min-p, typical, epsilon and eta cut-offs."""
+    import copy
+    import random
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM, LogitsProcessor, LogitsProcessorList
+    from visualcla.logits_processors import build_logits_processors, new_token_budget
+    torch.manual_seed(0)
+    V, H = 29, 32
+    m = LlamaForCausalLM(LlamaConfig(vocab_size=V, hidden_size=H, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                                     max_position_embeddings=64, pad_token_id=None, bos_token_id=None, eos_token_id=None)).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(5.0)
+
+    class Bump(LogitsProcessor):                              # a caller's own processor
+        def __call__(self, ids, scores):
+            s = scores.clone()
+            s[:, 11] += 0.5
+            return s
+
+    rng = random.Random(3)
+    checked = 0
+    for case in range(70):
+        B, T = rng.choice([1, 2, 3]), rng.choice([3, 6])
+        kw = {}
+        if rng.random() < 0.7:
+            kw["max_new_tokens"] = rng.choice([1, 3, 6, 9])
+        elif rng.random() < 0.7:
+            kw["max_length"] = T + rng.choice([1, 4, 8])
+        eos = rng.choice([None, 3, [3, 7]])
+        kw.update(eos_token_id=eos, pad_token_id=rng.choice([None, 0]))
+        for name, prob, val in (("min_new_tokens", 0.3, rng.choice([1, 2, 4])), ("min_length", 0.3, rng.choice([T + 2, 2, T + 5])), ("repetition_penalty", 0.3, 1.2),
+                                ("no_repeat_ngram_size", 0.3, 2), ("bad_words_ids", 0.3, [[5], [6, 8]]), ("sequence_bias", 0.2, [[[4], 2.0], [[9, 10], -3.0]]),
+                                ("suppress_tokens", 0.2, [12, 13]), ("begin_suppress_tokens", 0.2, [14, 1]), ("forced_bos_token_id", 0.15, 2),
+                                ("remove_invalid_values", 0.2, True), ("renormalize_logits", 0.3, True), ("encoder_repetition_penalty", 0.2, 1.3)):
+            if rng.random() < prob:
+                kw[name] = val
+        if eos is not None and rng.random() < 0.2:
+            kw["forced_eos_token_id"] = 3
+        if eos is not None and rng.random() < 0.2:
+            kw["exponential_decay_length_penalty"] = (1, 1.5)
+        kw["do_sample"] = rng.random() < 0.5
+        if kw["do_sample"]:
+            for name, prob, val in (("temperature", 0.5, rng.choice([0.5, 1.7])), ("top_k", 0.5, rng.choice([3, 10])), ("top_p", 0.5, 0.8), ("min_p", 0.3, 0.05),
+                                    ("typical_p", 0.3, 0.7), ("epsilon_cutoff", 0.3, 0.02), ("eta_cutoff", 0.3, 0.03)):
+                if rng.random() < prob:
+                    kw[name] = val
+        extra = [Bump()] if rng.random() < 0.3 else []
+        fn = (lambda b, sent: list(range(1, V - 2))) if rng.random() < 0.25 else None
+        emb = torch.randn(B, T, H, generator=torch.Generator().manual_seed(case))
+        mask = torch.ones(B, T, dtype=torch.long)
+        gc = GenerationConfig(**kw)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.manual_seed(case)
+            try:
+                ref = m.generate(inputs_embeds=emb, attention_mask=mask, generation_config=copy.deepcopy(gc), logits_processor=LogitsProcessorList(extra),
+                                 prefix_allowed_tokens_fn=fn, return_dict_in_generate=True, output_scores=True)
+            except RuntimeError:                              # a draw whose filters leave torch.multinomial nothing to sample from upstream
+                continue
+            seq, scores = ref.sequences, ref.scores
+            n_new = new_token_budget(gc, T)
+            procs = build_logits_processors(gc, [] if eos is None else ([eos] if isinstance(eos, int) else list(eos)), "cpu", prompt_len=T, n_new=n_new,
+                                            extra=extra, prefix_allowed_tokens_fn=fn)
+            assert len(scores) == seq.shape[1] <= n_new, (case, kw)
+            assert seq.shape[1] == n_new or eos is not None, (case, kw)
+            for i in range(seq.shape[1]):
+                e = torch.cat([emb, m.get_input_embeddings()(seq[:, :i])], 1)
+                s = m(inputs_embeds=e, attention_mask=torch.cat([mask, torch.ones(B, i, dtype=torch.long)], 1)).logits[:, -1].float()
+                for p in procs:
+                    s = p(seq[:, :i], s)
+                assert torch.equal(torch.isinf(s), torch.isinf(scores[i])), (case, i, kw, [type(p).__name__ for p in procs])
+                fin = ~torch.isinf(s)
+                assert torch.allclose(s[fin], scores[i][fin], rtol=1e-4, atol=1e-4, equal_nan=True), (case, i, kw, [type(p).__name__ for p in procs])   # upstream's own nan (length decay on a masked eos) included
+        checked += 1
+    assert checked >= 60
+
+
+def test_generation_config_fields_are_honoured_or_refused_never_dropped():
+    """the length rules of HF generate under `inputs_embeds` (generation/utils.py `_prepare_generated_length`), which fields send a request to the host-driven
+    path, and that every generation feature without an implementation is refused BY NAME (as is an unknown keyword, HF's `_validate_model_kwargs`)"""
+    sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
+    from transformers import GenerationConfig
+    from visualcla.logits_processors import min_token_floor, needs_host_processors, new_token_budget, refuse_unsupported
+    G = GenerationConfig
+    assert new_token_budget(G(max_new_tokens=7, max_length=3), 100) == 7          # max_new_tokens wins
+    assert new_token_budget(G(max_length=140), 128) == 12                          # an explicit max_length counts the prompt
+    assert new_token_budget(G(), 128) == 20
+    for ml in (128, 100):
+        with pytest.raises(ValueError, match="max_length"):
+            new_token_budget(G(max_length=ml), 128)
+    assert min_token_floor(G(min_new_tokens=5, min_length=500), 128) == 5
+    assert min_token_floor(G(min_length=130), 128) == 2 and min_token_floor(G(min_length=0), 128) == 0 and min_token_floor(G(), 128) == 0
+    assert not needs_host_processors(G(do_sample=True, top_k=40, top_p=0.9, temperature=0.5, repetition_penalty=1.1, no_repeat_ngram_size=15, min_length=0))
+    assert not needs_host_processors(G(do_sample=False, min_p=0.1, typical_p=0.5))          # warpers without sampling do nothing upstream either
+    for kw in (dict(bad_words_ids=[[3]]), dict(suppress_tokens=[3]), dict(begin_suppress_tokens=[3]), dict(forced_eos_token_id=2), dict(renormalize_logits=True),
+               dict(sequence_bias=[[[4], 1.0]]), dict(do_sample=True, min_p=0.1), dict(do_sample=True, typical_p=0.5), dict(do_sample=True, eta_cutoff=0.1),
+               dict(exponential_decay_length_penalty=(2, 1.1)), dict(remove_invalid_values=True)):
+        assert needs_host_processors(G(**kw)), kw
+    refuse_unsupported(G(max_new_tokens=3, do_sample=True, top_k=5, num_beams=4, length_penalty=0.5, use_cache=True), {})
+    for kw, word in ((dict(guidance_scale=1.5), "guidance_scale"), (dict(penalty_alpha=0.6, top_k=4), "penalty_alpha"), (dict(return_dict_in_generate=True), "return_dict"),
+                     (dict(return_dict_in_generate=True, output_scores=True), "output_scores"), (dict(stop_strings=["a"]), "stop_strings")):
+        with pytest.raises(ValueError, match=word):
+            refuse_unsupported(G(**kw), {})
+    with pytest.raises(ValueError, match="streamer"):
+        refuse_unsupported(G(), {"streamer": object()})

@@ -670,32 +670,19 @@ class VisualCLAModel:
             return []
         return [int(x) for x in e] if isinstance(e, (list, tuple)) else [int(e)]
 
-    def _processors(self, gc, extra_processors):
-        from transformers.generation import logits_process as LP
-        procs = []
-        eos = self._eos_list(gc)
-        if gc.repetition_penalty is not None and gc.repetition_penalty != 1.0:
-            procs.append(LP.RepetitionPenaltyLogitsProcessor(penalty=gc.repetition_penalty))
-        if gc.no_repeat_ngram_size is not None and gc.no_repeat_ngram_size > 0:
-            procs.append(LP.NoRepeatNGramLogitsProcessor(gc.no_repeat_ngram_size))
-        mnt = getattr(gc, "min_new_tokens", None)
-        if mnt and eos:
-            procs.append(LP.MinNewTokensLengthLogitsProcessor(0, mnt, eos, device=str(self._device)))
-        if extra_processors:
-            procs.extend(list(extra_processors))
-        if gc.do_sample:
-            if gc.temperature is not None and gc.temperature != 1.0:
-                procs.append(LP.TemperatureLogitsWarper(gc.temperature))
-            if gc.top_k is not None and gc.top_k != 0:
-                procs.append(LP.TopKLogitsWarper(top_k=gc.top_k))
-            if gc.top_p is not None and gc.top_p < 1.0:
-                procs.append(LP.TopPLogitsWarper(top_p=gc.top_p))
-        return procs
+    def _processors(self, gc, extra_processors, prompt_len: int = 0, n_new: Optional[int] = None, prefix_allowed_tokens_fn=None):
+        """the request's logits processors: transformers' classes in transformers' order (visualcla/logits_processors.py)"""
+        from .logits_processors import build_logits_processors
+        return build_logits_processors(gc, self._eos_list(gc), self._device, prompt_len=prompt_len, n_new=n_new, extra=extra_processors,
+                                       prefix_allowed_tokens_fn=prefix_allowed_tokens_fn)
 
-    def _device_sampling(self, gc, n_new: int):
+    def _device_sampling(self, gc, n_new: int, prompt_len: int = 0):
         """kwargs for _lib.sample_args when the generation config maps onto the on-device sampler (next row N2), else None"""
+        from .logits_processors import min_token_floor, needs_host_processors
+        if needs_host_processors(gc):
+            return None
         eos = self._eos_list(gc)
-        mnt = int(getattr(gc, "min_new_tokens", None) or 0) if eos else 0
+        mnt = min_token_floor(gc, prompt_len) if eos else 0       # min_new_tokens, or min_length less the prompt: the same eos mask
         if len(eos) > _lib.SAMPLE_MAX_EOS and mnt:
             return None
         if n_new > _lib.SAMPLE_MAX_HIST or self.config.text_config["vocab_size"] > _lib.SAMPLE_MAX_VOCAB:
@@ -721,18 +708,17 @@ class VisualCLAModel:
         top-p) through vcla_sample, drawing from torch.rand(n_new, B) of the device generator.  Custom logits processors,
         stopping criteria (streaming), `prefix_allowed_tokens_fn` or top_k = 0 take the host-driven path (HF processors +
         torch.multinomial)."""
+        from .logits_processors import refuse_unsupported
         gc = self._resolve_generation_config(generation_config, kwargs)
+        refuse_unsupported(gc, kwargs)                            # nothing the caller switched on is dropped silently
         nb = int(gc.num_beams or 1)
         if nb > 1 and gc.do_sample:
             raise ValueError("beam search is implemented for do_sample=False (beam SAMPLING draws without replacement from an implementation-defined "
                              "stream upstream); pass do_sample=False with num_beams > 1")
         if nb == 1 and (gc.num_return_sequences or 1) != 1:
             raise ValueError("num_return_sequences > 1 needs num_beams >= num_return_sequences")
-        if prefix_allowed_tokens_fn is not None:
-            # the reference forwards it to HF generate (modeling_visualcla.py:382-391), which turns it into this processor; it sees the
-            # NEW tokens only, as every processor does when HF is driven by inputs_embeds.  Host-driven step path.
-            from transformers.generation.logits_process import PrefixConstrainedLogitsProcessor
-            logits_processor = list(logits_processor or []) + [PrefixConstrainedLogitsProcessor(prefix_allowed_tokens_fn, num_beams=1)]
+        # prefix_allowed_tokens_fn: the reference forwards it to HF generate (modeling_visualcla.py:382-391), which turns it into a processor placed
+        # among the configured ones (it sees the NEW tokens only, as every processor does when HF is driven by inputs_embeds).  Host-driven step path.
         t = self.config.text_config
         input_ids = self._prepare_ids(input_ids, pixel_values)
         B = input_ids.shape[0]
@@ -749,12 +735,12 @@ class VisualCLAModel:
             side.wait_stream(cur_stream)
         with torch.cuda.device(self._device), torch.cuda.stream(side if side is not None else cur_stream):
             toks = self._generate_on_stream(gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph,
-                                            device_sampling)
+                                            device_sampling, prefix_allowed_tokens_fn)
         if side is not None:
             cur_stream.wait_stream(side)
         return toks
 
-    def _beam_generate(self, gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria):
+    def _beam_generate(self, gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria, prefix_fn=None):
         """num_beams > 1 (the reference forwards it to HF generate, modeling_visualcla.py:382-391).  As HF does with `inputs_embeds`, every prompt's
         spliced embeddings are repeated num_beams times AFTER the vision stack ran once per image; the prefill and every decode step run on the
         B * num_beams rows through the same kernels as any batch of that size (host-driven steps), the K / V cache rows are re-ordered to the
@@ -785,13 +771,14 @@ class VisualCLAModel:
                                                       _lib.ptr(key_mask), step_logits.data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
             state["pos"] = pos + 1
             return step_logits
-        procs = self._processors(gc, logits_processor)       # repetition penalty / no-repeat-ngram / min-new-tokens / caller's processors, on log-probs as HF
+        procs = self._processors(gc, logits_processor, T, n_new, prefix_fn)       # the configured + the caller's processors, applied to log-probs as HF does
         return beam_search(first, step, B, nb, n_new, eos_ids=eos, pad_token_id=gc.pad_token_id, length_penalty=float(gc.length_penalty if gc.length_penalty is not None else 1.0),
                            early_stopping=gc.early_stopping if gc.early_stopping is not None else False,
                            num_return_sequences=int(gc.num_return_sequences or 1), processors=procs,
                            stopping_criteria=list(stopping_criteria) if stopping_criteria else ())
 
-    def _generate_on_stream(self, gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph, device_sampling):
+    def _generate_on_stream(self, gc, input_ids, pixel_values, attention_mask, logits_processor, stopping_criteria, use_graph, device_sampling,
+                            prefix_fn=None):
         lib = _lib.load()
         t = self.config.text_config
         B = input_ids.shape[0]
@@ -802,31 +789,31 @@ class VisualCLAModel:
         embeds, extra = self._embed(input_ids, img, img_pos, _persistent=persistent)
         T = embeds.shape[1]
         max_pos = t["max_position_embeddings"]
-        if gc.max_new_tokens is not None:
-            n_new = int(gc.max_new_tokens)
-        else:
-            n_new = max(int(gc.max_length or 20), 1)
-        n_new = min(n_new, max_pos - T)
+        from .logits_processors import new_token_budget
+        n_new = min(new_token_budget(gc, T), max_pos - T)         # max_new_tokens, else max_length less the prompt, else 20 (HF's rules for inputs_embeds)
         if n_new <= 0:
             raise ValueError(f"prompt of {T} tokens leaves no room under max_position_embeddings={max_pos}")
         ctx_max = min(max_pos, (T + n_new + 63) // 64 * 64)
         eos = self._eos_list(gc)
         if int(gc.num_beams or 1) > 1:
-            return self._beam_generate(gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria)
+            return self._beam_generate(gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria, prefix_fn)
         cache = self._new_cache(B, ctx_max, _persistent=persistent)
         key_mask = self._key_mask(am, B, T, ctx_max)
         logits = self._prefill(embeds, cache, key_mask, all_logits=False, _persistent=persistent)
 
         pad_id = gc.pad_token_id if gc.pad_token_id is not None else (eos[0] if eos else 0)
-        procs = self._processors(gc, logits_processor)
+        procs = self._processors(gc, logits_processor, T, n_new, prefix_fn)
         criteria = list(stopping_criteria) if stopping_criteria else []
+        if getattr(gc, "max_time", None) is not None:
+            from transformers.generation.stopping_criteria import MaxTimeCriteria
+            criteria.append(MaxTimeCriteria(max_time=gc.max_time))
         ws = self._buf("llama", lib.vcla_llama_workspace_bytes(self._ctx, B, 1))
         stream = _lib.stream_ptr()
 
         plain_greedy = not procs and not gc.do_sample
         samp_kw = None
-        if not plain_greedy and not logits_processor and device_sampling is not False:
-            samp_kw = self._device_sampling(gc, n_new)
+        if not plain_greedy and not logits_processor and prefix_fn is None and device_sampling is not False:
+            samp_kw = self._device_sampling(gc, n_new, T)
         if device_sampling and samp_kw is None and not plain_greedy:
             raise ValueError("device_sampling=True but the generation config needs HF's processors on the host-driven path "
                              "(custom logits_processor, or top_k outside [1, %d])" % _lib.SAMPLE_MAX_TOP_K)
@@ -877,7 +864,7 @@ class VisualCLAModel:
         done = torch.zeros(B, dtype=torch.bool, device=self._device)
         eos_t = torch.tensor(eos, device=self._device) if eos else None
         step_logits = torch.empty(B, t["vocab_size"], dtype=torch.float32, device=self._device)
-        dev_select = not logits_processor and device_sampling is not False and (plain_greedy or samp_kw is not None)
+        dev_select = not logits_processor and prefix_fn is None and device_sampling is not False and (plain_greedy or samp_kw is not None)
         samp = None
         if dev_select and not plain_greedy:
             self._uniforms = torch.rand(n_new, B, device=self._device) if gc.do_sample else None
