@@ -647,3 +647,52 @@ def test_generation_config_fields_are_honoured_or_refused_never_dropped():
             refuse_unsupported(G(**kw), {})
     with pytest.raises(ValueError, match="streamer"):
         refuse_unsupported(G(), {"streamer": object()})
+
+
+def test_ring_gemm_loops_hold_no_vmem_the_hand_count_does_not_know():
+    """gemm_ring_kernel (csrc/gemm_ring.hip) waits for its LDS-DMA stages with hand-counted `s_waitcnt vmcnt((NS - 2) * PP)` over inline-asm
+    `global_load_lds_dwordx4` that hipcc does not see: vmcnt retires in order, so ONE compiler-emitted VMEM instruction (an epilogue load hoisted over the
+    loop, a scratch spill) between the first DMA and the last would shift every count and a stage would be read before it lands.  Audits every shipped
+    instantiation: up to its last DMA instruction the kernel issues no other global / buffer / scratch / flat instruction, and the waits it contains are
+    exactly the counts the source derives from the template parameters (PP = pieces per wave and stage, dummies included)."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(ROOT, "visual-chinese-llama-alpaca_amd", "visualcla", "libvisualcla_hip.so")
+    if not (os.path.exists(so) and all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump", "llvm-readelf"))):
+        pytest.skip("library not built or ROCm LLVM tools absent")
+    seen = 0
+    with tempfile.TemporaryDirectory() as td:
+        fb = os.path.join(td, "fat.bin")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", so])
+        data = open(fb, "rb").read()
+        offs = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+        for k, o in enumerate(offs):
+            bf, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"b{k}.co")
+            with open(bf, "wb") as f:
+                f.write(data[o:offs[k + 1] if k + 1 < len(offs) else len(data)])
+            subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={bf}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            syms = sorted(set(re.findall(r"\.name:\s+(_Z16gemm_ring_kernel\S+)", notes)))
+            if not syms:
+                continue
+            dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+            for sym in syms:
+                m = re.match(r"_Z16gemm_ring_kernelILi(\d+)E[tf]Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", sym)
+                assert m, sym
+                _, BM, BN, _, _, NS, KS, W8, _ = (int(x) for x in m.groups())
+                i = dis.index(f"<{sym}>:")
+                body = [ln.split("//")[0].strip() for ln in dis[i:dis.find("\n\n", i)].splitlines()[1:]]
+                vmem = [(n, ln) for n, ln in enumerate(body) if re.match(r"(global_|buffer_|scratch_|flat_)", ln)]
+                dma = [n for n, ln in vmem if ln.startswith("global_load_lds_dwordx4")]
+                pp = KS * (-(-(BM // 8) // 8) + -(-(BN // (16 if W8 else 8)) // 8))          # 1 KiB pieces per slab: BM / 8 of A, BN / 8 of bf16 W (BN / 16 of e4m3), over 8 waves
+                assert len(dma) >= 2 * pp, (sym, len(dma))
+                strangers = [ln for n, ln in vmem if n < dma[-1] and not ln.startswith("global_load_lds_dwordx4")]
+                assert not strangers, f"{sym}: VMEM instructions the hand count does not know, before the last DMA: {strangers[:4]}"
+                waits = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(body[:dma[-1] + 1]))}
+                want = {(NS - 2) * pp} | ({(NS - 1) * pp} if W8 else set())
+                assert want <= waits <= want | {0}, (sym, waits, want)
+                seen += 1
+    assert seen >= 20, seen
