@@ -273,25 +273,6 @@ def main():
                 same = torch.equal(out, ref)
                 print(f"slab256 {tag:16s} {nm} M={M:6d} N={N:6d} K={K:6d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:5.1f}% of peak)  {'== row-major result' if same else 'DIFFERS'}")
             del ws, w_sls
-    if "ringx" in which:
-        print("== ring kernel variants (experiment build: make -C visual-chinese-llama-alpaca_amd/csrc ringx; VCLA_LIB=tools/libvcla_ringx.so), M = 256, bf16 weights")
-        print("   var 0 = DMA burst behind the barrier, 1 = DMA spread over the MFMA groups, 2 = nt weights, 3 = both; ablations (garbage results): 16 / 17 = no reads / MFMAs")
-        print("   (burst / spread), 32 = no weight DMA, 48 = no activation DMA")
-        for tag, N, K, epi in (("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate-up", 22016, 4096, 3), ("down", 4096, 11008, 0)):
-            a = rnd(256, K)
-            ws = [packw(N, K) for _ in range(8)]
-            n_out = N // 2 if epi == 3 else N
-            out = torch.empty(256, n_out, dtype=torch.bfloat16, device=DEV)
-            for var in (0, 1, 2, 3, 16, 17, 32, 48):
-                os.environ["VCLA_RING_VAR"] = str(var)
-                for fk in ((11,) if epi == 3 else (11, 12, 13, 14)):
-                    def run():
-                        for w in ws:
-                            _lib.gemm(a, w, N, epilogue=epi, out=out, force_kernel=fk)
-                    t = timeit(run, reps=10) / len(ws)
-                    print(f"ringx {tag:8s} var={var:2d} k{fk} N={N:6d} K={K:6d}  {t*1e6:8.1f} us")
-            os.environ["VCLA_RING_VAR"] = "0"
-            del ws
     if "vit" in which:
         print("== ViT GEMMs at B=64 through AUTO dispatch (256x256 whole rounds + 64-row tail) vs forced kernels")
         Mv = 64 * 257
