@@ -696,3 +696,37 @@ def test_ring_gemm_loops_hold_no_vmem_the_hand_count_does_not_know():
                 assert want <= waits <= want | {0}, (sym, waits, want)
                 seen += 1
     assert seen >= 20, seen
+
+
+def test_generation_config_resolution_follows_transformers_priority():
+    """user keywords > the passed generation_config > the model's own generation config (every field left at None, not only the special tokens):
+    hf generation/utils.py `_prepare_generation_config`, which the reference reaches through text_model.generate.  Compared field by field with what a
+    tiny HF LLaMA resolves for the same three inputs."""
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM
+    from visualcla.modeling_visualcla import VisualCLAModel
+    own = GenerationConfig(bos_token_id=1, eos_token_id=2, pad_token_id=0, temperature=0.6, top_p=0.9, repetition_penalty=1.05)
+    hf = LlamaForCausalLM(LlamaConfig(vocab_size=16, hidden_size=16, intermediate_size=32, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2))
+    hf.generation_config = own
+    stub = SimpleNamespace(generation_config=own)
+    fields = ("max_new_tokens", "max_length", "min_length", "do_sample", "temperature", "top_k", "top_p", "repetition_penalty", "no_repeat_ngram_size",
+              "num_beams", "eos_token_id", "bos_token_id", "pad_token_id", "length_penalty", "bad_words_ids")
+    from visualcla.modeling_visualcla import _HF_GLOBAL_GENERATION_DEFAULTS
+    if hasattr(own, "_get_default_generation_params"):
+        upstream = own._get_default_generation_params()
+        assert all(upstream[k] == v for k, v in _HF_GLOBAL_GENERATION_DEFAULTS.items()), {k: (v, upstream.get(k)) for k, v in _HF_GLOBAL_GENERATION_DEFAULTS.items()}
+    for passed, kw in ((None, {}), (None, dict(max_new_tokens=5, do_sample=True, top_k=7)), (None, dict(do_sample=True)),
+                       (GenerationConfig(max_new_tokens=9, do_sample=True, top_k=40, temperature=0.5, eos_token_id=None), {}),
+                       (GenerationConfig(max_new_tokens=9, top_p=0.5, no_repeat_ngram_size=3), dict(eos_token_id=None, temperature=1.3, num_beams=2)),
+                       (GenerationConfig(eos_token_id=[2, 5], pad_token_id=7, bad_words_ids=[[3]]), dict(max_length=30))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want, _ = hf._prepare_generation_config(passed, **dict(kw))
+        got = VisualCLAModel._resolve_generation_config(stub, passed, dict(kw))
+        for f in fields:
+            w, g = getattr(want, f, None), getattr(got, f, None)
+            if f in ("max_length", "min_length") and g is None:
+                assert w == {"max_length": 20, "min_length": 0}[f]        # "not set" stays None here: visualcla.logits_processors' length rules test for it
+                continue
+            assert g == w, (f, passed, kw, g, w)                         # incl. the global defaults (top_k = 50!) and an explicit eos_token_id=None keyword

@@ -54,6 +54,15 @@ class _Embedding:
         raise RuntimeError("token embedding is fused into vcla_embed_splice; call VisualCLAModel.forward/generate")
 
 
+# transformers' global generation defaults (GenerationConfig._get_default_generation_params in 5.x; the attribute defaults of GenerationConfig before),
+# for the fields this path reads; applied to whatever the caller's and the model's configs leave at None, as hf generation/utils.py
+# `_prepare_generation_config` does
+_HF_GLOBAL_GENERATION_DEFAULTS = dict(do_sample=False, num_beams=1, temperature=1.0, top_k=50, top_p=1.0, typical_p=1.0, repetition_penalty=1.0,
+                                      length_penalty=1.0, no_repeat_ngram_size=0, num_return_sequences=1, early_stopping=False, epsilon_cutoff=0.0,
+                                      eta_cutoff=0.0, num_beam_groups=1, diversity_penalty=0.0, encoder_repetition_penalty=1.0,
+                                      encoder_no_repeat_ngram_size=0, remove_invalid_values=False, use_cache=True)
+
+
 class VisualCLAModel:
     config_class = VisualCLAConfig
     base_model_prefix = "visualcla"
@@ -651,13 +660,21 @@ class VisualCLAModel:
         import copy
         gc = copy.deepcopy(generation_config or self.generation_config or GenerationConfig())
         if generation_config is not None and self.generation_config is not None:
-            # HF generate(): special-token fields the caller's config leaves at None come from the model's own generation
-            # config (hf:generation/utils.py _prepare_generation_config) -- without this chat() under the reference's
-            # DEFAULT_GENERATION_CONFIG (eos_token_id=None) would never stop at </s>.  Explicit keyword arguments below
-            # still override (eos_token_id=None in a call disables the stop, as the benchmark does).
-            for k in ("eos_token_id", "bos_token_id", "pad_token_id"):
-                if getattr(gc, k, None) is None and getattr(self.generation_config, k, None) is not None:
-                    setattr(gc, k, getattr(self.generation_config, k))
+            # HF generate(): every field the caller's config leaves at None comes from the model's own generation config -- the text model's
+            # generation_config.json, since the reference calls text_model.generate (hf:generation/utils.py _prepare_generation_config:
+            # `update(**self.generation_config.to_dict(), defaults_only=True, allow_custom_entries=True)`).  Without this chat() under the
+            # reference's DEFAULT_GENERATION_CONFIG (eos_token_id=None) would never stop at </s>.  Explicit keyword arguments below still
+            # override (eos_token_id=None in a call disables the stop, as the benchmark does).
+            for k, v in self.generation_config.to_dict().items():
+                if k.startswith("_") or k == "transformers_version" or v is None:
+                    continue
+                if getattr(gc, k, None) is None:
+                    setattr(gc, k, copy.deepcopy(v))
+        # ... then transformers' global defaults for what is still None (same function; max_length / min_length stay None = "not set", which is what
+        # the length rules in logits_processors.py test).  Note top_k = 50: sampling without an explicit top_k is top-50 sampling upstream.
+        for k, v in _HF_GLOBAL_GENERATION_DEFAULTS.items():
+            if getattr(gc, k, None) is None:
+                setattr(gc, k, v)
         for k in list(kwargs.keys()):
             if hasattr(gc, k) and k not in ("input_ids", "pixel_values", "attention_mask"):
                 setattr(gc, k, kwargs.pop(k))
