@@ -453,6 +453,11 @@ def test_generation_config_fields_reach_the_decode_loop_or_are_refused():
     a = m.generate(max_new_tokens=6, min_length=T + 4, **dict(base, eos_token_id=stop, pad_token_id=0)).cpu()
     b = m.generate(max_new_tokens=6, min_new_tokens=4, **dict(base, eos_token_id=stop, pad_token_id=0)).cpu()
     assert torch.equal(a, b) and not bool((a[:, :4] == stop).any())
+    # several sampled sequences per prompt (rows b * n .. + n - 1 = prompt b); top_k = 1 makes every draw the greedy token
+    rep = m.generate(max_new_tokens=6, num_return_sequences=3, top_k=1, **dict(base, do_sample=True)).cpu()
+    assert rep.shape == (6, 6) and torch.equal(rep, want.repeat_interleave(3, dim=0))
+    free = m.generate(max_new_tokens=6, num_return_sequences=3, temperature=3.0, **dict(base, do_sample=True)).cpu()     # top_k: the global default 50
+    assert free.shape == (6, 6) and (not torch.equal(free[0], free[1]) or not torch.equal(free[1], free[2]))
     # refused by name, never dropped
     for kw, word in ((dict(return_dict_in_generate=True), "return_dict_in_generate"), (dict(penalty_alpha=0.5, top_k=4), "penalty_alpha"),
                      (dict(guidance_scale=2.0), "guidance_scale"), (dict(streamer=object()), "streamer"), (dict(max_new_token=3), "max_new_token")):

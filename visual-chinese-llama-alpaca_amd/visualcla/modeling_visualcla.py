@@ -732,8 +732,9 @@ class VisualCLAModel:
         if nb > 1 and gc.do_sample:
             raise ValueError("beam search is implemented for do_sample=False (beam SAMPLING draws without replacement from an implementation-defined "
                              "stream upstream); pass do_sample=False with num_beams > 1")
-        if nb == 1 and (gc.num_return_sequences or 1) != 1:
-            raise ValueError("num_return_sequences > 1 needs num_beams >= num_return_sequences")
+        if nb == 1 and (gc.num_return_sequences or 1) != 1 and not gc.do_sample:
+            # HF's wording (generation/configuration_utils.py validate): several returned sequences need beams or sampling
+            raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {gc.num_return_sequences}).")
         # prefix_allowed_tokens_fn: the reference forwards it to HF generate (modeling_visualcla.py:382-391), which turns it into a processor placed
         # among the configured ones (it sees the NEW tokens only, as every processor does when HF is driven by inputs_embeds).  Host-driven step path.
         t = self.config.text_config
@@ -804,6 +805,14 @@ class VisualCLAModel:
         img_pos, am = self._check_request(input_ids, attention_mask, Q, for_generate=True)       # one host sync; raises before any kernel runs
         img = self.embed_images(pixel_values, _persistent=persistent) if pixel_values is not None else None
         embeds, extra = self._embed(input_ids, img, img_pos, _persistent=persistent)
+        nrs = int(gc.num_return_sequences or 1)
+        if nrs > 1 and int(gc.num_beams or 1) == 1:
+            # sampling with several returned sequences: as HF does with inputs_embeds, every prompt's spliced embeddings are repeated num_return_sequences
+            # times AFTER the vision stack ran once per image (rows b * nrs .. + nrs - 1 = prompt b) and each row draws on its own.  Fresh buffers per call:
+            # the graph-replayed stages are keyed on persistent addresses.
+            embeds = embeds.repeat_interleave(nrs, dim=0).contiguous()
+            am = None if am is None else am.repeat_interleave(nrs, dim=0)
+            B, persistent, use_graph = B * nrs, False, False
         T = embeds.shape[1]
         max_pos = t["max_position_embeddings"]
         from .logits_processors import new_token_budget
