@@ -469,15 +469,18 @@ def test_check_request_validates_in_one_pass_on_cpu():
 
 def test_beam_search_bookkeeping_equals_transformers_on_random_configs():
     """visualcla.beam_search (host bookkeeping of generate(num_beams > 1)) against transformers' own beam search -- what the reference's generate() forwards
-    to (models/visualcla/modeling_visualcla.py:382-391) -- on a tiny random LLaMA driven by `inputs_embeds`: 80 random draws over batch, left padding, beams,
+    to (models/visualcla/modeling_visualcla.py:382-391) -- on a tiny random LLaMA driven by `inputs_embeds`: 100 random draws over batch, left padding, beams,
     length limits, eos sets the model really produces (one, two, five ids), pad ids (unset / 0 / another), length penalties (incl. 0 and negative),
-    early_stopping in {False, True, "never"}, several returned hypotheses, repetition penalty and no-repeat-ngram processors.  Ids must be EQUAL.  The step
+    early_stopping in {False, True, "never"}, several returned hypotheses, and the config-selected processors built by visualcla.logits_processors
+    (repetition penalty, no-repeat-ngram, eos floor, bad words, suppressed tokens, forced eos, a prefix_allowed_tokens_fn that depends on the prompt
+    index).  Ids must be EQUAL.  The step
     function here re-runs the full forward of the re-ordered sequences (no cache): the cache gather is covered by the golden-fixture tests."""
     import random
     import warnings
     sys.path.insert(0, os.path.join(ROOT, "visual-chinese-llama-alpaca_amd"))
-    from transformers import LlamaConfig, LlamaForCausalLM, LogitsProcessorList, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM
     from visualcla.beam_search import beam_search
+    from visualcla.logits_processors import build_logits_processors
     torch.manual_seed(0)
     V, H = 23, 32
     cfg = LlamaConfig(vocab_size=V, hidden_size=H, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
@@ -505,7 +508,7 @@ def test_beam_search_bookkeeping_equals_transformers_on_random_configs():
 
     rng = random.Random(1)
     hit_eos = finished_early = 0
-    for case in range(80):
+    for case in range(100):
         B, T, nb, L = rng.choice([1, 2, 3]), rng.choice([3, 5, 8]), rng.choice([2, 3, 4, 5]), rng.choice([1, 2, 4, 7, 10])
         eos = rng.choice([(), (3,), (3, 7), (1, 2, 3, 4, 5)])
         pad = rng.choice([None, 0, 9])
@@ -516,21 +519,31 @@ def test_beam_search_bookkeeping_equals_transformers_on_random_configs():
         mask = torch.ones(B, T, dtype=torch.long)
         for b in range(B):
             mask[b, :rng.choice([0, 0, 1, 2])] = 0
-        procs = LogitsProcessorList(([RepetitionPenaltyLogitsProcessor(rp)] if rp else []) + ([NoRepeatNGramLogitsProcessor(ng)] if ng else []))
         kw = dict(num_beams=nb, max_new_tokens=L, do_sample=False, length_penalty=lp, early_stopping=es, num_return_sequences=nrs,
                   eos_token_id=list(eos) if eos else None, pad_token_id=pad)
         if rp:
             kw["repetition_penalty"] = rp
         if ng:
             kw["no_repeat_ngram_size"] = ng
+        # the processors come from the package's own config -> processor mapping, with the fields a beam request may carry
+        fn = (lambda b, sent: [t for t in range(V) if (t + b) % 5 != 0]) if rng.random() < 0.3 else None      # depends on the PROMPT index: checks the beam -> prompt mapping
+        if eos and rng.random() < 0.3:
+            kw["min_new_tokens"] = 2
+        if rng.random() < 0.3:
+            kw["bad_words_ids"] = [[4], [6, 8]]
+        if rng.random() < 0.2:
+            kw["suppress_tokens"] = [10]
+        if eos and rng.random() < 0.2:
+            kw["forced_eos_token_id"] = eos[0]
+        procs = build_logits_processors(GenerationConfig(**kw), list(eos), "cpu", prompt_len=T, n_new=L, prefix_allowed_tokens_fn=fn)
         with torch.no_grad(), warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            ref = m.generate(inputs_embeds=emb, attention_mask=mask, **kw)
+            ref = m.generate(inputs_embeds=emb, attention_mask=mask, prefix_allowed_tokens_fn=fn, **kw)
             got = ours(emb, mask, nb, L, eos, pad, lp, es, nrs, procs)
         assert ref.shape == got.shape and torch.equal(ref, got), (case, kw, ref, got)
         hit_eos += int(bool(eos) and bool(torch.isin(ref, torch.tensor(list(eos) or [-5])).any()))
         finished_early += int(ref.shape[1] < L)
-    assert hit_eos >= 10 and finished_early >= 5             # the draw really exercises finished hypotheses
+    assert hit_eos >= 10 and finished_early >= 4             # the draw really exercises finished hypotheses
 
 
 def test_logits_processors_equal_transformers_on_random_configs():
