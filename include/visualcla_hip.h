@@ -419,6 +419,14 @@ int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_in, int B, 
                                    size_t ws_bytes, int use_graph, const vcla_sample_args* sampling, int n_hist0,
                                    void* stream);
 
+/* ABI v5.  At B = 1 (bf16, LLaMA-7B geometry, "llama.engine.w" / "llama.engine.g" registered) a decode step is ONE persistent launch
+   (csrc/decode_engine.hip) that replaces the per-token loop body of hf generation/utils.py reached from
+   models/visualcla/modeling_visualcla.py:382-391.  Its workgroups exchange operator outputs inside the launch and bound every wait; this call
+   synchronises `stream` and returns VCLA_ERR_HIP (vcla_last_error() names the wait site and the CU) when a wait of any step since the
+   workspace was last handed to vcla_llama_decode_step / _loop ran out -- the tokens of that loop are then invalid.  VCLA_OK otherwise, and
+   always when the steps ran as separate launches (VCLA_ENGINE=0, other batch sizes, fp8 weights). */
+int vcla_llama_decode_status(vcla_ctx* ctx, int B, const void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

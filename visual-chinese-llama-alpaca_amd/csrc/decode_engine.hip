@@ -1,0 +1,635 @@
+// decode_engine.hip -- ONE persistent launch per B = 1 decode step (bf16, LLaMA-7B geometry): the 32 decoder layers and the lm_head.
+//
+// Replaces the 161-launch step of engine.hip's `llama_layer` GEMV branch (per layer: qkv GEMV, fused attention, o_proj GEMV, gate/up GEMV,
+// down GEMV; spec: hf llama/modeling_llama.py:284-325 under the per-token loop of generation/utils.py that
+// /root/reference/models/visualcla/modeling_visualcla.py:382-391 enters).  Why: at B = 1 every launch pays its own ramp (x staging, the first
+// HBM round trip, the drain) and the weight stream idles during the attention -- 2.66 ms per token for 13.4 GB = 63 % of the HBM peak although
+// the long GEMVs alone reach 74 %.  MI355X_MICROARCH.md ("engine-vs-launches", "prefetch-credit", "ldsdma-fill") measures the structure used here:
+//   * 256 workgroups, one per CU, 4 waves each: wave 0 is a LOADER, waves 1 - 3 are CONSUMERS;
+//   * the loader streams its CU's share of ALL weights of the step -- one contiguous region of the engine twin ("llama.engine.w", built by
+//     weights.add_engine_stream: [CU][slot][16 KiB] in consumption order) -- with non-temporal `global_load_lds_dwordx4` into an 8 x 16 KiB LDS
+//     ring.  It knows nothing about operators: it runs ahead across every dependency edge until the ring is full (the prefetch credit);
+//   * a consumer wave takes a landed slot, multiplies it against the operator's input vector (bf16 in registers / LDS, `v_dot2c_f32_bf16`),
+//     reduces over the wave and publishes the outputs;
+//   * operator outputs travel between CUs as 8-byte {epoch tag, two bf16} granules: ONE relaxed agent-scope (sc1, write-through) store per
+//     granule, swept by ONE consumer wave per CU with relaxed agent-scope loads until every tag matches -- the data is the flag, no fences;
+//   * while its CU sweeps, the loader keeps only one fill in flight (the sweep's loads queue behind the CU's own DMA);
+//   * the attention of head h runs on the consumers of CU 8 h + h % 8 (one per head, spread over the XCDs) while every loader keeps
+//     prefetching wo / wgu.
+// Row ownership (so that no operator needs more than the all-gather of its input vector): CU c owns q / k / v rows h*128 + s*16 .. + 15 of
+// head h = c / 8, s = c % 8; rows 16 c .. + 15 of o_proj and down_proj (so the residual of its outputs is what it produced itself two
+// operators earlier); SwiGLU units upc * c .. ; lm_head rows 2 s_lm c ...  down_proj's K dimension is stored in granule order (44 slots per
+// producer CU: 43 activations + one zero), so the gathered activation mailbox IS its input vector.
+// Values: bf16 between operators exactly where the launch path rounds (qkv, attention output, both residual sums, SwiGLU output); the
+// RMSNorm output is rounded to bf16 once, as x * rstd * gamma (HF rounds it twice; the launch path keeps it in fp32): inside the bf16 bounds
+// the 7B parity tests state.  Every spin is bounded; a timeout records a site code in the workspace and lets every wave run out.
+#include "decode_engine.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void* eg_lds_ptr_t;
+typedef __attribute__((address_space(1))) unsigned long long eg_gu64;
+typedef __attribute__((ext_vector_type(2))) __bf16 eg_bf16x2_t;
+
+#define EG_RING_BYTES (8 * EG_SLOT)
+#define EG_XIN_BYTES 22528                 // 11264 bf16: the widest operator input (down_proj in granule order)
+#define EG_MISC_OFF (EG_RING_BYTES + EG_XIN_BYTES)
+#define EG_LDS_BYTES (EG_MISC_OFF + 4096)
+#define EG_SPIN_LDS (1u << 22)             // ~0.4 s of LDS polls
+#define EG_SPIN_GLB (1u << 17)             // ~0.2 s of mailbox sweeps
+
+struct EgMisc {                            // LDS words shared by the four waves (single writer each)
+    unsigned filled;                       // loader: number of slots that have landed (monotonic)
+    unsigned freed[8];                     // consumers: ring position p holds (g + 1) of the last slot released there
+    unsigned xin_ready;                    // leader: sequence number of the operator whose input vector is staged
+    unsigned cons_done[3];                 // consumer w: sequence number of the last operator it finished
+    unsigned attn_ready, attn_done[3];
+    unsigned gathering;                    // leader: a mailbox sweep is running (the loader thins itself)
+    unsigned fail;
+    unsigned pad_[13];                     // the 32 words above are zeroed at kernel start
+    float resid0[16], resid1[16];          // the CU's 16 rows of the layer input x / of x + o_proj(...) (bf16 values)
+    float dpart[3][16];                    // down_proj: per-consumer partial sums of the CU's 16 rows
+    unsigned qpk[64];                      // attention: roped q, packed bf16 pairs
+    float knew[128], vnew[128];
+    float part[3][132];                    // per-consumer (o[128], m, l)
+};
+static_assert(sizeof(EgMisc) <= 4096, "misc region");
+
+__device__ __forceinline__ unsigned eg_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void eg_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void eg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void eg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+
+__device__ __forceinline__ void eg_dma16_nt(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void eg_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// a failed wait: remember where (first failure wins), tell the workgroup
+__device__ __forceinline__ void eg_fail(EgMisc* m, unsigned* state, unsigned code) {
+    eg_st(&m->fail, code);
+    if ((threadIdx.x & 63) == 0) atomicCAS(state + 1, 0u, code | (blockIdx.x << 16));
+}
+// wait until *p >= need (LDS word written by another wave of this workgroup)
+__device__ __forceinline__ bool eg_wait_ge(const unsigned* p, unsigned need, EgMisc* m, unsigned* state, unsigned code) {
+    for (unsigned it = 0;; ++it) {
+        if (eg_ld(p) >= need) return true;
+        if ((it & 63) == 63 && eg_ld(&m->fail)) return false;
+        if (it > EG_SPIN_LDS) { eg_fail(m, state, code); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int CTRL> __device__ __forceinline__ float eg_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row ends up with the total
+__device__ __forceinline__ float eg_row_sum(float v) {
+    v += eg_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += eg_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += eg_dpp<0x141>(v);     // row_half_mirror
+    v += eg_dpp<0x140>(v);     // row_mirror
+    return v;
+}
+// sum over the wave; every lane ends up with the total (v_permlane16_swap / v_permlane32_swap: no SGPR round trip, no LDS)
+__device__ __forceinline__ float eg_wave_sum(float v) {
+    v = eg_row_sum(v);
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const auto s = __builtin_amdgcn_permlane16_swap(b, b, false, false);       // rows (0, 0, 2, 2) | (1, 1, 3, 3)
+    v = __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+    const unsigned c = __builtin_bit_cast(unsigned, v);
+    const auto t = __builtin_amdgcn_permlane32_swap(c, c, false, false);       // halves (lo, lo) | (hi, hi)
+    return __builtin_bit_cast(float, (unsigned)t[0]) + __builtin_bit_cast(float, (unsigned)t[1]);
+}
+// 8 bf16 x 8 bf16 on v_dot2c_f32_bf16.  (Pairs are taken with shufflevector from the whole vector: __builtin_bit_cast of an ext-vector ELEMENT is
+// miscompiled by this clang -- every element collapses to .x; see attention_decode.hip.)
+#define EG_PAIR(v, i) __builtin_shufflevector(v, v, 2 * (i), 2 * (i) + 1)
+// four independent accumulators (one per dword of the 16-byte piece)
+__device__ __forceinline__ void eg_dot8(const u32x4_t& w, const u32x4_t& x, float (&acc)[4]) {
+    const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w), b = __builtin_bit_cast(bf16x8_t, x);
+    acc[0] = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 0), EG_PAIR(b, 0), acc[0], false);
+    acc[1] = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 1), EG_PAIR(b, 1), acc[1], false);
+    acc[2] = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 2), EG_PAIR(b, 2), acc[2], false);
+    acc[3] = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 3), EG_PAIR(b, 3), acc[3], false);
+}
+__device__ __forceinline__ float eg_dot8s(const u32x4_t& w, const u32x4_t& x, float acc) {
+    const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w), b = __builtin_bit_cast(bf16x8_t, x);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 0), EG_PAIR(b, 0), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 1), EG_PAIR(b, 1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 2), EG_PAIR(b, 2), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(EG_PAIR(a, 3), EG_PAIR(b, 3), acc, false);
+    return acc;
+}
+__device__ __forceinline__ float eg_lo(unsigned d) { return __uint_as_float(d << 16); }
+__device__ __forceinline__ float eg_hi(unsigned d) { return __uint_as_float(d & 0xffff0000u); }
+
+__device__ __forceinline__ void eg_publish(unsigned long long* mb, int idx, unsigned epoch, unsigned data) {
+    __hip_atomic_store((eg_gu64*)(mb + idx), ((unsigned long long)epoch << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long eg_peek(const unsigned long long* mb, int idx) {
+    return __hip_atomic_load((const eg_gu64*)(mb + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// everything a consumer wave carries around
+struct EgCtx {
+    const vcla_engine_args* a;
+    unsigned char* ring;
+    unsigned char* xin;
+    EgMisc* m;
+    unsigned* state;
+    int w, lane, cu;
+    unsigned eb;              // epoch base of this launch
+    int pos;                  // position of the token being decoded = number of cached keys
+};
+__device__ __forceinline__ unsigned eg_epoch(const EgCtx& c, int layer, int edge) { return c.eb + (unsigned)(layer * 8 + edge); }
+__device__ __forceinline__ unsigned long long* eg_mb(const EgCtx& c, int layer, int off) {
+    return c.a->mbox + (size_t)(layer & 1) * EG_MB_PER_PARITY + off;
+}
+
+// ---- sweep N16 x 1024 granules starting at mb (ONE wave): v[k] = data of granule lane + 64 k
+template <int NCH>
+__device__ __forceinline__ bool eg_sweep(EgCtx& c, const unsigned long long* mb, unsigned epoch, unsigned (&v)[NCH * 16], int n_gran, unsigned code) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        for (unsigned it = 0;; ++it) {
+            bool good = true;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int idx = c.lane + 64 * (ch * 16 + k);
+                const int idc = idx < n_gran ? idx : n_gran - 1;           // past the end: re-read the last granule (tag checked like any other)
+                const unsigned long long x = eg_peek(mb, idc);
+                v[ch * 16 + k] = (unsigned)x;
+                good = good && (unsigned)(x >> 32) == epoch;
+            }
+            if (__all(good)) break;
+            if ((it & 15) == 15 && eg_ld(&c.m->fail)) return false;
+            if (it > EG_SPIN_GLB) { eg_fail(c.m, c.state, code); return false; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    return true;
+}
+
+// ---- leader: stage RMSNorm(x) * gamma (bf16) as the next operator's input.  x = the 2048-granule mailbox `mb`, or x_in (plain memory, layer 0)
+__device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long* mb, unsigned epoch, const float* gamma, bool from_mem) {
+    float2 gm[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) gm[k] = *reinterpret_cast<const float2*>(gamma + 2 * (c.lane + 64 * k));
+    unsigned v[32];
+    if (from_mem) {
+        const unsigned* xi = reinterpret_cast<const unsigned*>(c.a->x_in);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = xi[c.lane + 64 * k];
+    } else {
+        eg_st(&c.m->gathering, 1);
+        const bool good = eg_sweep<2>(c, mb, epoch, v, 2048, 0x11);
+        eg_st(&c.m->gathering, 0);
+        if (!good) return false;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float x0 = eg_lo(v[k]), x1 = eg_hi(v[k]); ss += x0 * x0 + x1 * x1; }
+    ss = eg_wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)EG_D + c.a->eps);
+    unsigned* xo = reinterpret_cast<unsigned*>(c.xin);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) xo[c.lane + 64 * k] = pack_bf2(eg_lo(v[k]) * rstd * gm[k].x, eg_hi(v[k]) * rstd * gm[k].y);
+    if (from_mem && c.lane < 16) c.m->resid0[c.lane] = bf2f(c.a->x_in[16 * c.cu + c.lane]);
+    return true;
+}
+// ---- leader: stage a gathered mailbox as it is (attention output: 2048 granules; SwiGLU activations: 256 * gpc granules), 1024 granules at a time
+__device__ __forceinline__ bool eg_stage_raw(EgCtx& c, const unsigned long long* mb, unsigned epoch, int n_gran, unsigned code) {
+    unsigned* xo = reinterpret_cast<unsigned*>(c.xin);
+    eg_st(&c.m->gathering, 1);
+    bool good = true;
+    for (int base = 0; base < n_gran && good; base += 1024) {
+        unsigned v[16];
+        const int n = n_gran - base < 1024 ? n_gran - base : 1024;
+        good = eg_sweep<1>(c, mb + base, epoch, v, n, code);
+        if (good) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int idx = c.lane + 64 * k;
+                if (idx < n) xo[base + idx] = v[k];
+            }
+        }
+    }
+    eg_st(&c.m->gathering, 0);
+    return good;
+}
+
+// ---- one landed slot of a row-major operator: two rows of 4096 weights against the x registers -> two wave-uniform sums
+__device__ __forceinline__ bool eg_slot2(EgCtx& c, int g, const u32x4_t (&xr)[8], float& t0, float& t1) {
+    if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, 0x21)) return false;
+    eg_acquire();
+    const unsigned char* base = c.ring + (g & 7) * EG_SLOT + c.lane * 16;
+    u32x4_t wv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) wv[p] = *reinterpret_cast<const u32x4_t*>(base + p * 1024);
+    eg_release();                                  // (waits for the reads above)
+    eg_st(&c.m->freed[g & 7], (unsigned)g + 1);
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { eg_dot8(wv[p], xr[p], a0); eg_dot8(wv[8 + p], xr[p], a1); }
+    t0 = eg_wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
+    t1 = eg_wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3]));
+    return true;
+}
+
+enum { EG_OP_QKV = 0, EG_OP_O = 1, EG_OP_GU = 2, EG_OP_LM = 3 };
+
+// ---- a row-major operator (K = 4096): the consumer's slots j = w, w + 3, ... of nslots starting at global slot g0 (gate/up: slot PAIRS)
+template <int OP>
+__device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int layer, unsigned seq) {
+    if (!eg_wait_ge(&c.m->xin_ready, seq, c.m, c.state, 0x22)) return false;
+    eg_acquire();
+    u32x4_t xr[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const u32x4_t*>(c.xin + p * 1024 + c.lane * 16);
+    const vcla_engine_args& a = *c.a;
+    if constexpr (OP == EG_OP_GU) {
+        const int gpc = (a.g.upc + 1) >> 1;
+        unsigned long long* mb = eg_mb(c, layer, EG_MB_ACT);
+        const unsigned ep = eg_epoch(c, layer, 4);
+        for (int jp = c.w; jp < gpc; jp += 3) {
+            float g_, u_, v0, v1 = 0.f;
+            if (!eg_slot2(c, g0 + 2 * jp, xr, g_, u_)) return false;
+            v0 = act_silu(g_) * u_;
+            if (2 * jp + 1 < nslots) {
+                if (!eg_slot2(c, g0 + 2 * jp + 1, xr, g_, u_)) return false;
+                v1 = act_silu(g_) * u_;
+            }
+            if (c.lane == 0) eg_publish(mb, gpc * c.cu + jp, ep, pack_bf2(v0, v1));
+        }
+    } else {
+        for (int j = c.w; j < nslots; j += 3) {
+            float t0, t1;
+            if (!eg_slot2(c, g0 + j, xr, t0, t1)) return false;
+            if constexpr (OP == EG_OP_QKV) {
+                const int part = j >> 3, jj = j & 7;
+                const int row = part * EG_D + (c.cu >> 3) * EG_HD + (c.cu & 7) * 16 + 2 * jj;
+                if (c.lane == 0) eg_publish(eg_mb(c, layer, EG_MB_QKV), row >> 1, eg_epoch(c, layer, 1), pack_bf2(t0, t1));
+            } else if constexpr (OP == EG_OP_O) {
+                const unsigned d = pack_bf2(t0 + c.m->resid0[2 * j], t1 + c.m->resid0[2 * j + 1]);
+                if (c.lane == 0) {
+                    c.m->resid1[2 * j] = eg_lo(d);
+                    c.m->resid1[2 * j + 1] = eg_hi(d);
+                    eg_publish(eg_mb(c, layer, EG_MB_X1), 8 * c.cu + j, eg_epoch(c, layer, 3), d);
+                }
+            } else {
+                const int row = 2 * a.g.s_lm * c.cu + 2 * j;
+                if (c.lane == 0) {
+                    if (row < a.g.vocab) a.logits[row] = t0;
+                    if (row + 1 < a.g.vocab) a.logits[row + 1] = t1;
+                }
+            }
+        }
+    }
+    eg_release();
+    eg_st(&c.m->cons_done[c.w], seq);
+    return true;
+}
+
+// ---- down_proj: K-major slots (16 rows x 512 k each); the leader adds the three consumers' partial sums and the residual, publishes x of the next layer
+__device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int layer, unsigned seq) {
+    if (!eg_wait_ge(&c.m->xin_ready, seq, c.m, c.state, 0x23)) return false;
+    eg_acquire();
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int j = c.w; j < nslots; j += 3) {
+        const int g = g0 + j;
+        if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, 0x24)) return false;
+        eg_acquire();
+        const unsigned char* base = c.ring + (g & 7) * EG_SLOT + c.lane * 16;
+        const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
+        u32x4_t wv[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) wv[p] = *reinterpret_cast<const u32x4_t*>(base + p * 1024);
+        eg_release();
+        eg_st(&c.m->freed[g & 7], (unsigned)g + 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = eg_dot8s(wv[i], xk, acc[i]);
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float t = eg_wave_sum(acc[i]); mine = c.lane == i ? t : mine; }
+    if (c.lane < 16) c.m->dpart[c.w][c.lane] = mine;
+    eg_release();
+    eg_st(&c.m->cons_done[c.w], seq);
+    if (c.w == 0) {
+        if (!eg_wait_ge(&c.m->cons_done[1], seq, c.m, c.state, 0x25) || !eg_wait_ge(&c.m->cons_done[2], seq, c.m, c.state, 0x26)) return false;
+        eg_acquire();
+        const int l = c.lane & 15;
+        const float v = (c.m->dpart[0][l] + c.m->dpart[1][l]) + c.m->dpart[2][l] + c.m->resid1[l];
+        const float vr = Act<bf16_t>::rnd(v);
+        const float nb = __shfl_down(vr, 1, 64);
+        if (c.lane < 16) c.m->resid0[c.lane] = vr;
+        if (c.lane < 16 && (c.lane & 1) == 0)
+            eg_publish(eg_mb(c, layer + 1, EG_MB_X), 8 * c.cu + (c.lane >> 1), eg_epoch(c, layer + 1, 0), pack_bf2(vr, nb));
+    }
+    return true;
+}
+
+// ---- attention of one head on this CU's three consumers (RoPE + cache append + single-pass online softmax over the cache; the arithmetic of
+// attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3)
+template <bool MASK>
+__device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
+    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = 8;
+    const vcla_engine_args& a = *c.a;
+    EgMisc* m = c.m;
+    const int h = c.cu >> 3, pos = c.pos, lane = c.lane;
+    const size_t per = (size_t)EG_H * a.ctx_max * D;
+    bf16_t* kbase = a.kv + (size_t)(2 * layer) * per + (size_t)h * a.ctx_max * D;
+    bf16_t* vbase = kbase + per;
+    const int32_t* km = a.key_mask;
+    const int cch = lane % LPK, grp = c.w * KPW + lane / LPK;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(kbase, 0, a.ctx_max * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vbase, 0, a.ctx_max * D * 2, 0x00020000);
+    u32x4_t kA[U], vA[U], kB[U], vB[U];
+    int mA[U], mB[U];
+    const int last = pos > 0 ? pos - 1 : 0;
+#define EG_FD_LOAD(KB_, VB_, MB_, t_)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
+        int j_ = grp + ((t_) * U + u) * KPB;                                                                         \
+        j_ = j_ < pos ? j_ : last;                                                                                   \
+        const unsigned off_ = (unsigned)(j_ * D * 2 + cch * 16);                                                     \
+        KB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rK, off_, 0, 2 /* nt */));         \
+        VB_[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, off_, 0, 2 /* nt */));         \
+        MB_[u] = MASK ? km[j_] : 1;                                                                                  \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    const int nb = (pos + U * KPB - 1) / (U * KPB);
+    if (nb > 0) {            // the cache rows do not depend on this step's q: requested before the qkv granules are even complete
+        EG_FD_LOAD(kA, vA, mA, 0)
+        EG_FD_LOAD(kB, vB, mB, 1)
+    }
+    const unsigned seq = (unsigned)layer + 1;
+    if (c.w == 0) {
+        // q / k / v of the head: 64 granules each (lane t holds elements 2 t, 2 t + 1; the rotate-half partner sits in lane t ^ 32)
+        const unsigned long long* mb = eg_mb(c, layer, EG_MB_QKV);
+        const unsigned ep = eg_epoch(c, layer, 1);
+        unsigned qd = 0, kd = 0, vd = 0;
+        eg_st(&m->gathering, 1);
+        for (unsigned it = 0;; ++it) {
+            const unsigned long long xq = eg_peek(mb, h * 64 + lane), xk = eg_peek(mb, 2048 + h * 64 + lane), xv = eg_peek(mb, 4096 + h * 64 + lane);
+            qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
+            const bool good = (unsigned)(xq >> 32) == ep && (unsigned)(xk >> 32) == ep && (unsigned)(xv >> 32) == ep;
+            if (__all(good)) break;
+            if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
+            if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x31); eg_st(&m->gathering, 0); return false; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        eg_st(&m->gathering, 0);
+        const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
+        const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * (D / 2) + i0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
+        const float c0 = Act<bf16_t>::rnd(cs.x), c1 = Act<bf16_t>::rnd(cs.y), s0 = Act<bf16_t>::rnd(sn.x), s1 = Act<bf16_t>::rnd(sn.y);
+        const bool hi_half = lane >= 32;
+        const float q0 = eg_lo(qd), q1 = eg_hi(qd), k0 = eg_lo(kd), k1 = eg_hi(kd);
+        const float pq0 = __shfl_xor(q0, 32, 64), pq1 = __shfl_xor(q1, 32, 64), pk0 = __shfl_xor(k0, 32, 64), pk1 = __shfl_xor(k1, 32, 64);
+        // first half: x * c - partner * s; second half: x * c + partner * s  (hf llama rotate_half; every product and sum rounded to bf16 once)
+        const float rq0 = Act<bf16_t>::rnd(hi_half ? q0 * c0 + pq0 * s0 : q0 * c0 - pq0 * s0);
+        const float rq1 = Act<bf16_t>::rnd(hi_half ? q1 * c1 + pq1 * s1 : q1 * c1 - pq1 * s1);
+        const float rk0 = Act<bf16_t>::rnd(hi_half ? k0 * c0 + pk0 * s0 : k0 * c0 - pk0 * s0);
+        const float rk1 = Act<bf16_t>::rnd(hi_half ? k1 * c1 + pk1 * s1 : k1 * c1 - pk1 * s1);
+        m->qpk[lane] = pack_bf2(rq0, rq1);
+        m->knew[2 * lane] = rk0; m->knew[2 * lane + 1] = rk1;
+        m->vnew[2 * lane] = eg_lo(vd); m->vnew[2 * lane + 1] = eg_hi(vd);
+        reinterpret_cast<unsigned*>(kbase + (size_t)pos * D)[lane] = pack_bf2(rk0, rk1);
+        reinterpret_cast<unsigned*>(vbase + (size_t)pos * D)[lane] = vd;
+        eg_release();
+        eg_st(&m->attn_ready, seq);
+    } else {
+        if (!eg_wait_ge(&m->attn_ready, seq, m, c.state, 0x32)) return false;
+    }
+    eg_acquire();
+    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(m->qpk + cch * 4);
+    const float sl2 = a.scale * 1.44269504088896340736f;
+    float m_run = -INFINITY, l_run = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#define EG_FD_COMPUTE(KB_, VB_, MB_, t_)                                                                             \
+    {                                                                                                                \
+        float s_[U];                                                                                                 \
+        float mb_ = -INFINITY;                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
+            const int j_ = grp + ((t_) * U + u) * KPB;                                                               \
+            const float d_ = eg_row_sum(eg_dot8s(qv, KB_[u], 0.f));                                                  \
+            s_[u] = (j_ < pos && MB_[u] != 0) ? d_ * sl2 : -INFINITY;                                                \
+            mb_ = fmaxf(mb_, s_[u]);                                                                                 \
+        }                                                                                                            \
+        const float mn_ = fmaxf(m_run, mb_);                                                                         \
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;                                                              \
+        const float al_ = __builtin_amdgcn_exp2f(m_run - mu_);                                                       \
+        m_run = mn_;                                                                                                 \
+        float ps_ = 0.f;                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] *= al_;                                                   \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                              \
+            const float p_ = __builtin_amdgcn_exp2f(s_[u] - mu_);                                                    \
+            ps_ += p_;                                                                                               \
+            float vv_[8];                                                                                            \
+            bf8_to_f32(make_uint4(VB_[u].x, VB_[u].y, VB_[u].z, VB_[u].w), vv_);                                     \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, vv_[e], o[e]);                   \
+        }                                                                                                            \
+        l_run = l_run * al_ + ps_;                                                                                   \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < nb; t += 2) {
+        EG_FD_COMPUTE(kA, vA, mA, t)
+        EG_FD_LOAD(kA, vA, mA, t + 2)
+        EG_FD_COMPUTE(kB, vB, mB, t + 1)
+        EG_FD_LOAD(kB, vB, mB, t + 3)
+    }
+#undef EG_FD_LOAD
+#undef EG_FD_COMPUTE
+    {   // the new token (key / value in LDS): every group computes it, group 0 of the workgroup folds it in
+        float d_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const unsigned qq = m->qpk[cch * 4 + e / 2];
+            d_ = __builtin_fmaf(eg_lo(qq), m->knew[cch * 8 + e], d_);
+            d_ = __builtin_fmaf(eg_hi(qq), m->knew[cch * 8 + e + 1], d_);
+        }
+        d_ = eg_row_sum(d_);
+        const float s_ = (grp == 0 && (!MASK || km[pos] != 0)) ? d_ * sl2 : -INFINITY;
+        const float mn_ = fmaxf(m_run, s_);
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+        const float al_ = __builtin_amdgcn_exp2f(m_run - mu_), p_ = __builtin_amdgcn_exp2f(s_ - mu_);
+        m_run = mn_;
+        l_run = l_run * al_ + p_;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p_, m->vnew[cch * 8 + e], o[e] * al_);
+    }
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {       // merge the 4 lane groups of the wave
+        const float m2 = __shfl_xor(m_run, off, 64), l2 = __shfl_xor(l_run, off, 64);
+        const float mn_ = fmaxf(m_run, m2);
+        const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+        const float a1 = __builtin_amdgcn_exp2f(m_run - mu_), a2 = __builtin_amdgcn_exp2f(m2 - mu_);
+        l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * a1 + __shfl_xor(o[e], off, 64) * a2;
+        m_run = mn_;
+    }
+    if (lane < LPK) {
+        float* pw = m->part[c.w];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pw[lane * 8 + e] = o[e];
+        if (lane == 0) { pw[D] = m_run; pw[D + 1] = l_run; }
+    }
+    eg_release();
+    eg_st(&m->attn_done[c.w], seq);
+    if (c.w == 0) {
+        if (!eg_wait_ge(&m->attn_done[1], seq, m, c.state, 0x33) || !eg_wait_ge(&m->attn_done[2], seq, m, c.state, 0x34)) return false;
+        eg_acquire();
+        if (lane < 16) {
+            float mf = fmaxf(fmaxf(m->part[0][D], m->part[1][D]), m->part[2][D]);
+            const float mu_ = mf == -INFINITY ? 0.f : mf;
+            float lf = 0.f, o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) {
+                const float* pw = m->part[w2];
+                const float a_ = __builtin_amdgcn_exp2f(pw[D] - mu_);
+                lf += pw[D + 1] * a_;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] += pw[lane * 8 + e] * a_;
+            }
+            const float inv = lf > 0.f ? 1.0f / lf : 0.f;
+            unsigned long long* mbo = eg_mb(c, layer, EG_MB_AO);
+            const unsigned epo = eg_epoch(c, layer, 2);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) eg_publish(mbo, h * 64 + lane * 4 + e / 2, epo, pack_bf2(o8[e] * inv, o8[e + 1] * inv));
+        }
+    }
+    return true;
+}
+
+template <bool MASK>
+__device__ __forceinline__ void eg_consumer(EgCtx& c) {
+    const vcla_engine_args& a = *c.a;
+    const vcla_engine_geom& G = a.g;
+    EgMisc* m = c.m;
+    const bool attn_cu = (c.cu & 7) == ((c.cu >> 3) & 7);
+    const int gpc = (G.upc + 1) >> 1;
+    // the leader may overwrite xin only when the other consumers have finished the operator that reads it
+    auto others_done = [&](unsigned seq) -> bool {
+        return eg_wait_ge(&m->cons_done[1], seq, m, c.state, 0x41) && eg_wait_ge(&m->cons_done[2], seq, m, c.state, 0x42);
+    };
+    auto ready = [&](unsigned seq) { eg_release(); eg_st(&m->xin_ready, seq); };
+    for (int l = 0; l < G.n_layers; ++l) {
+        const int g0 = l * G.slots_layer;
+        const unsigned s0 = (unsigned)l * 4 + 1;
+        if (c.w == 0) {
+            if (l > 0 && !others_done(s0 - 1)) return;
+            if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X), eg_epoch(c, l, 0), a.gamma + (size_t)(2 * l) * EG_D, l == 0)) return;
+            ready(s0);
+        }
+        if (!eg_run_rows<EG_OP_QKV>(c, g0, EG_S_QKV, l, s0)) return;
+        if (attn_cu && !eg_attention<MASK>(c, l)) return;
+        if (c.w == 0) {
+            if (!others_done(s0)) return;
+            if (!eg_stage_raw(c, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), 2048, 0x12)) return;
+            ready(s0 + 1);
+        }
+        if (!eg_run_rows<EG_OP_O>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1)) return;
+        if (c.w == 0) {
+            if (!others_done(s0 + 1)) return;
+            if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X1), eg_epoch(c, l, 3), a.gamma + (size_t)(2 * l + 1) * EG_D, false)) return;
+            ready(s0 + 2);
+        }
+        if (!eg_run_rows<EG_OP_GU>(c, g0 + EG_S_QKV + EG_S_O, G.upc, l, s0 + 2)) return;
+        if (c.w == 0) {
+            if (!others_done(s0 + 2)) return;
+            if (!eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13)) return;
+            ready(s0 + 3);
+        }
+        if (!eg_run_down(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3)) return;
+    }
+    const int L = G.n_layers;
+    const unsigned sl = (unsigned)L * 4 + 1;
+    if (c.w == 0) {
+        if (!others_done(sl - 1)) return;
+        if (!eg_stage_norm(c, eg_mb(c, L, EG_MB_X), eg_epoch(c, L, 0), a.gamma + (size_t)(2 * L) * EG_D, false)) return;
+        ready(sl);
+    }
+    if (!eg_run_rows<EG_OP_LM>(c, L * G.slots_layer, G.s_lm, L, sl)) return;
+    // the launch sequence number moves on once per successful launch (every workgroup read it before its first publish, and this store sits
+    // behind the last all-gather, which needed all of them)
+    if (c.cu == 0 && c.w == 0 && c.lane == 0) c.state[0] = (c.eb >> 10) + 1;
+}
+
+__device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ring_u, EgMisc* m, unsigned* state, int cu, int lane) {
+    const int total = a.g.slots_total;
+    const unsigned char* src = a.stream + (size_t)cu * (size_t)total * EG_SLOT + lane * 16;
+    unsigned pub = 0;
+    for (int g = 0; g < total; ++g) {
+        const int p = g & 7;
+        if (g >= 8 && eg_ld(&m->freed[p]) < (unsigned)(g - 7)) {
+            // ring full: nothing to issue, so everything issued may as well be published
+            eg_vmcnt<0>();
+            if (pub < (unsigned)g) { pub = g; eg_st(&m->filled, pub); }
+            if (!eg_wait_ge(&m->freed[p], (unsigned)(g - 7), m, state, 0x01)) break;
+        }
+        const unsigned dst = ring_u + p * EG_SLOT;
+        const unsigned char* s = src + (size_t)g * EG_SLOT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) eg_dma16_nt(s + i * 1024, dst + i * 1024);
+        unsigned landed;
+        if (eg_ld(&m->gathering)) { eg_vmcnt<16>(); landed = g; }          // thin: at most this fill in flight while the CU sweeps a mailbox
+        else { eg_vmcnt<48>(); landed = g >= 2 ? g - 2 : 0; }              // slots <= g - 3 have landed
+        if (landed > pub) { pub = landed; eg_st(&m->filled, pub); }
+    }
+    eg_vmcnt<0>();
+    eg_st(&m->filled, (unsigned)total);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 1) void decode_engine_kernel(vcla_engine_args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char eg_lds[];
+    EgMisc* m = reinterpret_cast<EgMisc*>(eg_lds + EG_MISC_OFF);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned* state = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.mbox) + EG_WS_STATE_OFF);
+    for (int i = threadIdx.x; i < 32; i += 256) reinterpret_cast<unsigned*>(m)[i] = 0u;      // the flag words
+    const unsigned seq = state[0];
+    const int pos = a.pos0 + (a.pos_dev ? *a.pos_dev : 0);
+    __syncthreads();
+    if (wave == 0) {
+        eg_loader(a, (unsigned)(uintptr_t)(eg_lds_ptr_t)eg_lds, m, state, blockIdx.x, lane);
+    } else {
+        EgCtx c;
+        c.a = &a; c.ring = eg_lds; c.xin = eg_lds + EG_RING_BYTES; c.m = m; c.state = state;
+        c.w = wave - 1; c.lane = lane; c.cu = blockIdx.x; c.eb = (seq << 10) + 1u; c.pos = pos;
+        eg_consumer<MASK>(c);
+    }
+}
+
+bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_layers, vcla_engine_geom* g) {
+    if (hidden != EG_D || heads != EG_H || inter <= 0 || inter % EG_NCU || n_layers <= 0 || n_layers > 120 || vocab <= 0) return false;
+    const int upc = inter / EG_NCU, gpc = (upc + 1) / 2;
+    if (EG_NCU * gpc > EG_MB_MAX_ACT) return false;
+    g->n_layers = n_layers; g->inter = inter; g->vocab = vocab;
+    g->upc = upc; g->s_dn = gpc;
+    g->s_lm = (vocab + 2 * EG_NCU - 1) / (2 * EG_NCU);
+    g->slots_layer = EG_S_QKV + EG_S_O + upc + gpc;
+    g->slots_total = n_layers * g->slots_layer + g->s_lm;
+    return true;
+}
+
+int vcla_engine_launch(const vcla_engine_args* a, hipStream_t s) {
+    static bool attr_set[2][VCLA_MAX_DEVICES] = {};
+    if (a->key_mask) {
+        const int rc = vcla_raise_dyn_lds((const void*)decode_engine_kernel<true>, EG_LDS_BYTES, attr_set[1]);
+        if (rc) return rc;
+        decode_engine_kernel<true><<<EG_NCU, 256, EG_LDS_BYTES, s>>>(*a);
+    } else {
+        const int rc = vcla_raise_dyn_lds((const void*)decode_engine_kernel<false>, EG_LDS_BYTES, attr_set[0]);
+        if (rc) return rc;
+        decode_engine_kernel<false><<<EG_NCU, 256, EG_LDS_BYTES, s>>>(*a);
+    }
+    VCLA_CHECK_LAUNCH("decode_engine_kernel");
+    return VCLA_OK;
+}

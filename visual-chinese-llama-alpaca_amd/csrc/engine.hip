@@ -9,6 +9,7 @@
 // Memory: nothing is allocated here.  Weights are caller-owned device tensors registered by name; activations
 // live in a caller-provided workspace carved by a bump allocator; the KV cache is caller-owned.
 #include "vcla_common.h"
+#include "decode_engine.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -129,6 +130,10 @@ struct vcla_ctx {
     const void* lm_head = nullptr;
     WVar vlm;
     const float *rope_cos = nullptr, *rope_sin = nullptr;
+    // the persistent B = 1 decode step (decode_engine.hip): its weight stream + norm gains, when registered and the geometry fits
+    const void* eng_w = nullptr;
+    const float* eng_g = nullptr;
+    vcla_engine_geom eng_geom = {};
     int k_pad = 0;  // padded im2col width
     // per-call state of the macro entry points (one thread drives a context at a time): the workspace carve of the
     // running call and what the last streaming GEMM left behind.  Kept here, not in thread-local globals, so that nothing
@@ -158,7 +163,7 @@ struct vcla_ctx {
         const void *ids, *kv, *mask, *ws, *out;
         int B, pos0, ctx_max, step_base;
         const void* pos_dev;
-        int has_samp, n_hist0;
+        int has_samp, n_hist0, engine;
         vcla_sample_args samp;
     } graph_key = {};
 };
@@ -362,6 +367,14 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
     const int d = c.t_hidden / c.t_heads;
     GET_F(ctx->rope_cos, "llama.rope_cos", (size_t)c.t_max_pos * (d / 2));
     GET_F(ctx->rope_sin, "llama.rope_sin", (size_t)c.t_max_pos * (d / 2));
+    ctx->eng_w = nullptr; ctx->eng_g = nullptr;
+    if (c.act_dtype == VCLA_BF16 && !c.t_kv_fp8 && vcla_engine_geometry(c.t_hidden, c.t_heads, c.t_inter, c.t_vocab, c.t_layers, &ctx->eng_geom)) {
+        const void *ew = nullptr, *eg = nullptr;
+        int rc = get_tensor_opt(ctx, "llama.engine.w", (size_t)EG_NCU * ctx->eng_geom.slots_total * EG_SLOT, &ew);
+        if (!rc) rc = get_tensor_opt(ctx, "llama.engine.g", (size_t)(2 * c.t_layers + 1) * EG_D * 4, &eg);
+        if (rc) return rc;
+        if (ew && eg) { ctx->eng_w = ew; ctx->eng_g = (const float*)eg; }
+    }
     ctx->finalized = true;
     return VCLA_OK;
 }
@@ -420,6 +433,7 @@ struct LlamaWs {
     void* q8;       // [M][max(t_hidden, t_inter)] fp8 copy of the activation operand (fp8 MFMA prefill, t_fp8_mfma)
     float* q8s;     // [M] its per-row scales
     int* ticket;    // arrival counter of post_select_kernel (zeroed by the decode loop before its first step)
+    void* eng;      // mailboxes + state words of the persistent decode step (EG_WS_BYTES; zeroed before the first step of a loop)
 };
 static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs* w) {
     const vcla_model_cfg& c = ctx->c;
@@ -438,6 +452,7 @@ static size_t carve_llama(const vcla_ctx* ctx, int B, int T, char* base, LlamaWs
     t.splitk = b.take(SPLITK_WS_BYTES);
     t.ssq = (float*)b.take((size_t)64 * ((c.t_hidden + 15) / 16) * 4);
     t.ticket = (int*)b.take(256);
+    t.eng = b.take(EG_WS_BYTES);
     t.q8 = nullptr; t.q8s = nullptr;
     if (c.t_fp8_mfma && (size_t)B * T > 128) {
         t.q8 = b.take(M * (size_t)(c.t_hidden > c.t_inter ? c.t_hidden : c.t_inter));
@@ -866,6 +881,20 @@ static int llama_prefill_impl(vcla_ctx* ctx, const void* inputs_embeds, int B, i
     return VCLA_OK;
 }
 
+// The persistent decode step serves B = 1 in the bf16 mode when its weight stream is registered, no fp8 decode copies are loaded (those
+// steps read the 1-byte weights) and the device is the 256-CU part the row ownership is laid out for.  VCLA_ENGINE=0: the launch path.
+static bool engine_step_ok(const vcla_ctx* ctx, int B) {
+    const char* eng_s = getenv("VCLA_ENGINE");        // read per call: A/B runs and the tests flip it inside one process
+    const int eng_env = eng_s ? atoi(eng_s) : 1;
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return n;
+    }();
+    return eng_env && B == 1 && ctx->eng_w && ctx->eng_g && ctx->c.act_dtype == VCLA_BF16 && !ctx->c.t_kv_fp8 && n_cu == EG_NCU &&
+           !(ctx->llama[0].vqkv.q8 && ctx->llama[0].vqkv.s8);
+}
+
 static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
                             int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
                             int64_t* ids_out, const LlamaWs& w, const vcla_sample_args* samp = nullptr, int n_hist0 = 0,
@@ -875,10 +904,19 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
     const int D = c.t_hidden;
     struct Scope { vcla_ctx* c; explicit Scope(vcla_ctx* c_) : c(c_) { c->run.decode_step = true; } ~Scope() { c->run.decode_step = false; } } decode_scope(ctx);
     if (!skip_embed) RUN(vcla_embed_splice(ids_in, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, D, c.t_vocab, dt, s));   // else: w.x was filled by post_select_kernel
+    float* lg = logits ? logits : w.logits;
+    if (engine_step_ok(ctx, B)) {
+        // B = 1, bf16, LLaMA-7B geometry: the whole step (32 layers + lm_head) is ONE persistent launch (decode_engine.hip)
+        vcla_engine_args ea{};
+        ea.g = ctx->eng_geom; ea.stream = (const unsigned char*)ctx->eng_w; ea.gamma = ctx->eng_g; ea.x_in = (const bf16_t*)w.x;
+        ea.kv = (bf16_t*)kv_cache; ea.ctx_max = ctx_max; ea.pos0 = pos0; ea.pos_dev = pos_dev; ea.key_mask = key_mask;
+        ea.rope_cos = ctx->rope_cos; ea.rope_sin = ctx->rope_sin; ea.scale = 1.0f / sqrtf((float)(D / c.t_heads)); ea.eps = c.t_eps;
+        ea.logits = lg; ea.mbox = (unsigned long long*)w.eng;
+        RUN(vcla_engine_launch(&ea, s));
+    } else {
     for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
                         l + 1 < c.t_layers ? ctx->llama[l + 1].ln1g : ctx->norm_g));
-    float* lg = logits ? logits : w.logits;
     static const int ds_env = getenv("VCLA_DSTREAM") ? atoi(getenv("VCLA_DSTREAM")) : 1;
     const LlamaLayer& L0 = ctx->llama[0];
     const bool ds_layers = ds_env && dt == VCLA_BF16 && B >= 2 && B <= 64 && D % 32 == 0 && c.t_inter % 32 == 0 &&
@@ -897,6 +935,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         RUN(gemm(ctx, s, w.x, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, ctx->norm_g, c.t_eps, &ctx->vlm));
     } else {
         RUN(gemm(ctx, s, w.h, D, ctx->lm_head, nullptr, nullptr, 0, lg, c.t_vocab, B, c.t_vocab, D, VCLA_EPI_NONE, 1, 0, 0, 0, nullptr, 0.f, &ctx->vlm));
+    }
     }
     if (ids_out && samp) RUN(vcla_sample_launch(lg, c.t_vocab, B, c.t_vocab, n_hist0, pos_dev, samp, ids_out, s));
     else if (ids_out) RUN(vcla_argmax(lg, c.t_vocab, ids_out, B, c.t_vocab, s));
@@ -925,6 +964,7 @@ extern "C" int vcla_llama_decode_step(vcla_ctx* ctx, const int64_t* ids_in, int 
     LlamaWs w;
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     ctx->run.splitk_ws = w.splitk;
+    if (engine_step_ok(ctx, B)) VCLA_CHECK_HIP(hipMemsetAsync(w.eng, 0, EG_WS_BYTES, (hipStream_t)stream));
     return decode_step_impl(ctx, (hipStream_t)stream, ids_in, B, pos0, pos_dev, advance_pos, kv_cache, ctx_max, key_mask,
                             logits, ids_out, w);
 }
@@ -958,6 +998,9 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     // (record the ids, embed them, advance the position: one launch instead of three per step).
     RUN(vcla_embed_splice(w.ids, ctx->embed, nullptr, nullptr, w.x, B, 1, 0, c.t_hidden, c.t_vocab, c.act_dtype, s));
     VCLA_CHECK_HIP(hipMemsetAsync(w.ticket, 0, 4, s));
+    // mailboxes + launch sequence of the persistent step: zero ONCE per loop (the launches tag their granules with the sequence number they
+    // read from the state words and advance it themselves, so the replayed graph needs no memset node)
+    if (engine_step_ok(ctx, B)) VCLA_CHECK_HIP(hipMemsetAsync(w.eng, 0, EG_WS_BYTES, s));
     auto one_step = [&](hipStream_t st) -> int {
         RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0, /*skip_embed=*/true));
         if (c.act_dtype == VCLA_BF16 && c.t_hidden % 8 == 0)
@@ -979,7 +1022,7 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     auto& k = ctx->graph_key;
     const bool same = ctx->graph_exec && k.ids == (const void*)w.ids && k.kv == kv_cache && k.mask == (const void*)key_mask &&
                       k.ws == ws && k.out == (const void*)ids_out && k.B == B && k.pos0 == pos0 && k.ctx_max == ctx_max &&
-                      k.pos_dev == (const void*)pos_dev && k.step_base == step_base && k.has_samp == (sampling != nullptr) &&
+                      k.pos_dev == (const void*)pos_dev && k.step_base == step_base && k.has_samp == (sampling != nullptr) && k.engine == (int)engine_step_ok(ctx, B) &&
                       (!sampling || (k.n_hist0 == n_hist0 && memcmp(&k.samp, sampling, sizeof(*sampling)) == 0));
     // several steps per graph launch (VCLA_GRAPH_STEPS=4): measured EQUAL to one step per launch on MI355X (B = 1: 359.7 vs 359.3
     // tok/s; the ~9 us between graph launches seen in round 1 are gone with the shorter step tail) -> off by default
@@ -1004,7 +1047,7 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
         RUN(capture(1, &ctx->graph_exec));
         k.ids = w.ids; k.kv = kv_cache; k.mask = key_mask; k.ws = ws; k.out = ids_out; k.B = B; k.pos0 = pos0;
         k.ctx_max = ctx_max; k.pos_dev = pos_dev; k.step_base = step_base;
-        k.has_samp = sampling != nullptr; k.n_hist0 = n_hist0;
+        k.has_samp = sampling != nullptr; k.n_hist0 = n_hist0; k.engine = (int)engine_step_ok(ctx, B);
         if (sampling) memcpy(&k.samp, sampling, sizeof(*sampling));
     }
     int left = n_steps;
@@ -1013,5 +1056,19 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
         for (; left >= G; left -= G) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec_multi, s));
     }
     for (; left > 0; --left) VCLA_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, s));
+    return VCLA_OK;
+}
+
+// The persistent decode step bounds every wait; a wait that ran out leaves (site code | CU << 16) in the workspace.  Synchronises the stream.
+extern "C" int vcla_llama_decode_status(vcla_ctx* ctx, int B, const void* ws, size_t ws_bytes, void* stream) {
+    VCLA_REQUIRE(ctx && ctx->finalized && ctx->c.t_layers > 0 && ws && B > 0, VCLA_ERR_BAD_ARG, "llama_decode_status: bad arguments");
+    VCLA_REQUIRE(ws_bytes >= vcla_llama_workspace_bytes(ctx, B, 1), VCLA_ERR_WORKSPACE, "llama_decode_status: workspace too small");
+    VCLA_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (!engine_step_ok(ctx, B)) return VCLA_OK;
+    LlamaWs w;
+    carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
+    unsigned st[2] = {0, 0};
+    VCLA_CHECK_HIP(hipMemcpy(st, (const char*)w.eng + EG_WS_STATE_OFF, sizeof st, hipMemcpyDeviceToHost));
+    if (st[1]) return vcla_fail(VCLA_ERR_HIP, "decode engine: a wait timed out (site 0x%x on CU %u after %u launches); its output is invalid", st[1] & 0xffffu, st[1] >> 16, st[0]);
     return VCLA_OK;
 }

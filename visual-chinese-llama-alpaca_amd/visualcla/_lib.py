@@ -144,6 +144,7 @@ SYMBOLS = {
     "vcla_llama_prefill": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "vcla_llama_decode_step": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vcla_llama_decode_loop": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+    "vcla_llama_decode_status": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vcla_llama_decode_loop_sampled": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _i, C.POINTER(SampleArgs), _i, _vp]),
 }
 

@@ -135,6 +135,76 @@ def add_fragment_copies(packed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
     return packed
 
 
+# ---- the persistent B = 1 decode engine's weight stream (csrc/decode_engine.hip) ------------------------------------------------------------
+ENGINE_NCU, ENGINE_D, ENGINE_H, ENGINE_SLOT = 256, 4096, 32, 16384      # one workgroup per CU of an MI355X; LLaMA-7B hidden = 32 heads x 128
+
+
+def engine_geometry(hidden: int, heads: int, inter: int, vocab: int, n_layers: int):
+    """Slot counts of the engine stream (mirrors vcla_engine_geometry, csrc/decode_engine.hip); None when the model cannot run on the engine."""
+    if hidden != ENGINE_D or heads != ENGINE_H or inter <= 0 or inter % ENGINE_NCU or not 0 < n_layers <= 120 or vocab <= 0:
+        return None
+    upc = inter // ENGINE_NCU
+    gpc = (upc + 1) // 2
+    if ENGINE_NCU * gpc > 5632:
+        return None
+    s_lm = (vocab + 2 * ENGINE_NCU - 1) // (2 * ENGINE_NCU)
+    slots_layer = 24 + 8 + upc + gpc
+    return dict(upc=upc, gpc=gpc, s_lm=s_lm, slots_layer=slots_layer, slots_total=n_layers * slots_layer + s_lm)
+
+
+def engine_down_kmap(inter: int) -> torch.Tensor:
+    """down_proj's K dimension in GRANULE order: producer CU c publishes gpc granules of two activations each (units upc*c + 2j, + 2j + 1; the
+    odd last one alone), and the consumers use the gathered mailbox as the input vector as it is.  kmap[k'] = real k, or -1 (zero column)."""
+    upc = inter // ENGINE_NCU
+    gpc = (upc + 1) // 2
+    c = torch.arange(ENGINE_NCU).view(-1, 1, 1)
+    j = torch.arange(gpc).view(1, -1, 1)
+    e = torch.arange(2).view(1, 1, -1)
+    local = 2 * j + e
+    k = upc * c + local
+    return torch.where(local < upc, k, torch.full_like(k, -1)).reshape(-1)
+
+
+def add_engine_stream(packed: Dict[str, torch.Tensor], hidden: int, heads: int, inter: int, vocab: int, n_layers: int) -> Dict[str, torch.Tensor]:
+    """`llama.engine.w` [256 CUs][slots_total][8192] bf16 + `llama.engine.g` [2 L + 1][4096] fp32: a THIRD copy of the LLaMA matrices (13.4 GB at
+    7B; HBM is 288 GB) in which every CU's share of every operator is one contiguous run of 16-KiB slots in the order the persistent decode step
+    consumes them -- its loader wave streams the region front to back without knowing what an operator is.  Per layer and CU c (head h = c // 8,
+    s = c % 8): 24 slots of wqkv (2 rows each: q, k, v rows h*128 + s*16 + 2j), 8 of wo (rows 16c + 2j), upc of wgu (gate row + up row of unit
+    upc*c + j), gpc of wd (K-major: 16 rows x 512 k', k' in granule order, engine_down_kmap); after the layers s_lm slots of lm_head (rows
+    2 s_lm c + 2j).  Nothing is added when the geometry does not fit (the launch path serves the model)."""
+    g = engine_geometry(hidden, heads, inter, vocab, n_layers)
+    if g is None or "llama.lm_head" not in packed:
+        return packed
+    D, N, upc, gpc, s_lm, SL = ENGINE_D, ENGINE_NCU, g["upc"], g["gpc"], g["s_lm"], g["slots_layer"]
+    dev = packed["llama.lm_head"].device
+    stream = torch.zeros(N, g["slots_total"], 2 * D, dtype=torch.bfloat16, device=dev)
+    kmap = engine_down_kmap(inter).to(dev)
+    ksrc = kmap.clamp_min(0)
+    kzero = (kmap < 0)
+    for l in range(n_layers):
+        d = f"llama.l{l}."
+        blk = stream[:, l * SL:(l + 1) * SL]
+        # wqkv [3D, D] -> [part, head, s, j, 2, D] -> [head, s, part, j, 2 D]
+        blk[:, 0:24] = packed[d + "wqkv"][:3 * D].view(3, ENGINE_H, 8, 8, 2, D).permute(1, 2, 0, 3, 4, 5).reshape(N, 24, 2 * D)
+        blk[:, 24:32] = packed[d + "wo"][:D].view(N, 8, 2 * D)
+        # wgu rows come in blocks (16 gate, 16 up): unit u = gate row u and up row u
+        blk[:, 32:32 + upc] = packed[d + "wgu"][:2 * inter].view(inter // 16, 2, 16, D).permute(0, 2, 1, 3).reshape(N, upc, 2 * D)
+        wd = packed[d + "wd"][:D].index_select(1, ksrc)
+        wd[:, kzero] = 0
+        blk[:, 32 + upc:32 + upc + gpc] = wd.view(N, 16, gpc, 512).permute(0, 2, 1, 3).reshape(N, gpc, 16 * 512)
+    lm = packed["llama.lm_head"]
+    rows = N * 2 * s_lm
+    lmp = torch.zeros(rows, D, dtype=torch.bfloat16, device=dev)
+    n = min(rows, lm.shape[0])
+    lmp[:n] = lm[:n]
+    lmp[vocab:] = 0
+    stream[:, n_layers * SL:] = lmp.view(N, s_lm, 2 * D)
+    gam = [packed[f"llama.l{l}.ln{i}.g"] for l in range(n_layers) for i in (1, 2)] + [packed["llama.norm.g"]]
+    packed["llama.engine.w"] = stream
+    packed["llama.engine.g"] = torch.stack(gam, 0).to(torch.float32).contiguous()
+    return packed
+
+
 def extend_position_embedding(state_dict: Dict[str, torch.Tensor], patch_size: int, after: int) -> Dict[str, torch.Tensor]:
     """Grow the CLIP position embedding for a larger input resolution (e.g. 224 -> 336 px, BASELINE configs[4]): the
     class-token row is kept, the g x g patch grid is bicubically interpolated to (after // patch_size)^2, position_ids are
@@ -304,6 +374,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg, device, act_dtype: torch.d
     out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
     if act_dtype == torch.bfloat16:
         add_fragment_copies(out)
+        add_engine_stream(out, t["hidden_size"], t["num_attention_heads"], t["intermediate_size"], t["vocab_size"], t["num_hidden_layers"])
     return out
 
 
@@ -369,6 +440,7 @@ def random_packed(cfg, device, act_dtype: torch.dtype, seed: int = 0) -> Dict[st
     out["llama.rope_cos"], out["llama.rope_sin"] = cos.to(device), sin.to(device)
     if act_dtype == torch.bfloat16:
         add_fragment_copies(out)
+        add_engine_stream(out, Dt, t["num_attention_heads"], It, V, t["num_hidden_layers"])
     return out
 
 
