@@ -29,6 +29,47 @@ def build(layers: int, vocab: int, inter: int):
     return visualcla.VisualCLAModel.from_random(cfg, device="cuda:0", torch_dtype=torch.bfloat16, seed=3)
 
 
+PHASES = ["stage x (gather + RMSNorm)", "qkv slots", "attention (attention CUs only)", "gather attn-out", "o_proj slots", "gather x1 + RMSNorm",
+          "gate/up slots", "gather activations", "down slots + finish"]
+
+
+def timeline(m, lib, embeds, T, ctx_max, a):
+    """One engine step with debug stamps (VCLA_ENGINE_TL): leader-wave wall-clock (100 MHz) at the phase boundaries of every layer and CU."""
+    dev = m._device
+    L = a.layers
+    os.environ["VCLA_ENGINE"] = "1"
+    tl = torch.zeros(256, 2048, dtype=torch.int64, device=dev)
+    os.environ["VCLA_ENGINE_TL"] = hex(tl.data_ptr())
+    cache = m._new_cache(1, ctx_max)
+    m._prefill(embeds, cache, None, all_logits=False)
+    ws = m._buf("llama", lib.vcla_llama_workspace_bytes(m._ctx, 1, 1))
+    tok = torch.tensor([17], device=dev)
+    lg = torch.empty(1, m.config.text_config["vocab_size"], dtype=torch.float32, device=dev)
+    for s in range(3):      # the last step's stamps are the ones read
+        _lib.check(lib.vcla_llama_decode_step(m._ctx, tok.data_ptr(), 1, T + s, None, 0, cache.kv.data_ptr(), ctx_max, None, lg.data_ptr(), None,
+                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        _lib.check(lib.vcla_llama_decode_status(m._ctx, 1, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    del os.environ["VCLA_ENGINE_TL"]
+    t = tl.cpu().double() * 0.01      # us
+    st = t[:, :L * 16].view(256, L, 16)[:, :, :10]
+    cu = torch.arange(256)
+    attn = (cu & 7) == ((cu >> 3) & 7)
+    d = st[:, :, 1:] - st[:, :, :-1]           # [256, L, 9] phase durations
+    lay = slice(1, L) if L > 1 else slice(0, 1)
+    print(f"engine timeline, one step, layers {lay.start}..{L - 1}, us (median over CUs | max over CUs; attention CUs / other CUs):")
+    for k, name in enumerate(PHASES):
+        da, do = d[attn][:, lay, k].flatten(), d[~attn][:, lay, k].flatten()
+        print(f"  {name:34s} attn-CU {da.median():6.2f} | {da.max():6.2f}    other {do.median():6.2f} | {do.max():6.2f}")
+    per_layer = (st[:, lay, 9] - st[:, lay, 0])
+    print(f"  layer, stamp 0 -> 9: median {per_layer.median():.2f} us, max {per_layer.max():.2f} us; whole step (loader begin -> end): "
+          f"{(t[:, 2041] - t[:, 2040]).median():.1f} us")
+    stall, ns = t[:, 2042], tl.cpu()[:, 2043].double()
+    print(f"  loader: ring-full stalls {ns.median():.0f} per CU, {stall.median():.1f} us stalled per CU (median) of the step; "
+          f"slots {a.layers * (32 + a.inter // 256 + (a.inter // 256 + 1) // 2)} + lm_head")
+    skew = st[:, lay, 1] - st[:, lay, 1].min(dim=0, keepdim=True).values
+    print(f"  skew of 'x staged' over CUs: median {skew.median():.2f} us, max {skew.max():.2f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=4)
@@ -38,6 +79,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=160, help="prompt length")
     ap.add_argument("--time", type=int, default=64, help="decode steps per timed loop (0: skip)")
     ap.add_argument("--mask", action="store_true", help="pass an all-ones key mask (the MASK instantiation)")
+    ap.add_argument("--timeline", action="store_true", help="print the per-phase wall-clock breakdown of one engine step (debug stamps)")
     a = ap.parse_args()
     lib = _lib.load()
     m = build(a.layers, a.vocab, a.inter)
@@ -79,8 +121,14 @@ def main():
         d = (l0[s] - l1[s]).abs()
         print(f"step {s}: logits std {l0[s].std().item():.3f}  |engine - launches| max {d.max().item():.4f} mean {d.mean().item():.5f}  "
               f"argmax {int(l0[s].argmax())} / {int(l1[s].argmax())}  finite {bool(torch.isfinite(l1[s]).all())}", flush=True)
-    kd = (results["0"][2].float() - results["1"][2].float()).abs()
-    print(f"K/V cache: max |diff| {kd.max().item():.4f} (bf16 values; rows written by both paths)", flush=True)
+    kd = (results["0"][2][..., :T + a.steps, :].float() - results["1"][2][..., :T + a.steps, :].float()).abs()
+    print(f"K/V cache: max |diff| {kd.max().item():.4f} over the {T + a.steps} rows both paths wrote", flush=True)
+    if a.timeline:
+        for pg in (0, 1):
+            os.environ["VCLA_ENGINE_PG"] = str(pg)
+            print(f"--- VCLA_ENGINE_PG={pg} (parallel activation gather)")
+            timeline(m, lib, embeds, T, ctx_max, a)
+        del os.environ["VCLA_ENGINE_PG"]
     if a.time > 0:
         for mode in ("0", "1", "0", "1"):
             os.environ["VCLA_ENGINE"] = mode

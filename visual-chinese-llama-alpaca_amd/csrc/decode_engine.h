@@ -20,6 +20,7 @@
 #define EG_MB_PER_PARITY (EG_MB_ACT + EG_MB_MAX_ACT)
 #define EG_WS_STATE_OFF ((size_t)2 * EG_MB_PER_PARITY * 8)           // state words behind the mailboxes: [0] launch sequence, [1] failure code
 #define EG_WS_BYTES (EG_WS_STATE_OFF + 256)
+#define EG_TL_STRIDE 2048      // debug stamps per CU: 16 per layer (leader), then loader totals at [2040..]
 
 struct vcla_engine_geom {
     int n_layers, inter, vocab;
@@ -44,6 +45,8 @@ struct vcla_engine_args {
     float scale, eps;
     float* logits;                 // [vocab] fp32
     unsigned long long* mbox;      // EG_WS_BYTES of workspace, zeroed by the caller before the FIRST step of a sequence of launches
+    int par_gather;                // != 0: the three consumers sweep the activation mailbox together (2 chunks each)
+    unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };
 
 int vcla_engine_launch(const vcla_engine_args* a, hipStream_t s);

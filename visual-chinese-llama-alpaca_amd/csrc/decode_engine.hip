@@ -45,7 +45,9 @@ struct EgMisc {                            // LDS words shared by the four waves
     unsigned attn_ready, attn_done[3];
     unsigned gathering;                    // leader: a mailbox sweep is running (the loader thins itself)
     unsigned fail;
-    unsigned pad_[13];                     // the 32 words above are zeroed at kernel start
+    unsigned x_taken[3];                   // consumer w: sequence number of the last operator whose input it copied out of xin
+    unsigned gath_done[3];                 // consumer w: sequence number of the last operator whose input chunks it staged
+    unsigned pad_[7];                     // the 32 words above are zeroed at kernel start
     float resid0[16], resid1[16];          // the CU's 16 rows of the layer input x / of x + o_proj(...) (bf16 values)
     float dpart[3][16];                    // down_proj: per-consumer partial sums of the CU's 16 rows
     unsigned qpk[64];                      // attention: roped q, packed bf16 pairs
@@ -146,8 +148,22 @@ __device__ __forceinline__ unsigned eg_epoch(const EgCtx& c, int layer, int edge
 __device__ __forceinline__ unsigned long long* eg_mb(const EgCtx& c, int layer, int off) {
     return c.a->mbox + (size_t)(layer & 1) * EG_MB_PER_PARITY + off;
 }
+// The layer loop is one huge function after inlining, and LICM hoists every lane- / wave- / CU-derived address of every phase in front of it, where
+// they stay live across all phases and crowd out the slot registers.  Re-defining the three roots at the start of a phase makes everything derived
+// from them local to the phase.  (Through a VGPR + readfirstlane: an "s" asm operand needs a value hipcc can PROVE uniform.)
+__device__ __forceinline__ void eg_fresh(EgCtx& c) {
+    asm volatile("" : "+v"(c.lane));
+    int w = c.w, cu = c.cu;
+    asm volatile("" : "+v"(w), "+v"(cu));
+    c.w = __builtin_amdgcn_readfirstlane(w);
+    c.cu = __builtin_amdgcn_readfirstlane(cu);
+}
+// debug stamps (timeline != NULL only): lane 0 of the leader wave of every CU
+__device__ __forceinline__ void eg_stamp(const EgCtx& c, int layer, int k) {
+    if (c.a->timeline && c.lane == 0) c.a->timeline[(size_t)c.cu * EG_TL_STRIDE + layer * 16 + k] = wall_clock64();
+}
 
-// ---- sweep N16 x 1024 granules starting at mb (ONE wave): v[k] = data of granule lane + 64 k
+// ---- sweep NCH x 1024 granules starting at mb (ONE wave): v[k] = data of granule lane + 64 k
 template <int NCH>
 __device__ __forceinline__ bool eg_sweep(EgCtx& c, const unsigned long long* mb, unsigned epoch, unsigned (&v)[NCH * 16], int n_gran, unsigned code) {
 #pragma unroll
@@ -198,12 +214,12 @@ __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long
     if (from_mem && c.lane < 16) c.m->resid0[c.lane] = bf2f(c.a->x_in[16 * c.cu + c.lane]);
     return true;
 }
-// ---- leader: stage a gathered mailbox as it is (attention output: 2048 granules; SwiGLU activations: 256 * gpc granules), 1024 granules at a time
-__device__ __forceinline__ bool eg_stage_raw(EgCtx& c, const unsigned long long* mb, unsigned epoch, int n_gran, unsigned code) {
+// ---- stage a gathered mailbox as it is (attention output: 2048 granules; SwiGLU activations: 256 * gpc granules), 1024 granules at a time:
+// chunks first, first + step, ...  (the leader alone: 0, 1; all three consumers together: w, 3)
+__device__ __forceinline__ bool eg_stage_raw(EgCtx& c, const unsigned long long* mb, unsigned epoch, int n_gran, unsigned code, int first, int step) {
     unsigned* xo = reinterpret_cast<unsigned*>(c.xin);
-    eg_st(&c.m->gathering, 1);
     bool good = true;
-    for (int base = 0; base < n_gran && good; base += 1024) {
+    for (int base = first * 1024; base < n_gran && good; base += step * 1024) {
         unsigned v[16];
         const int n = n_gran - base < 1024 ? n_gran - base : 1024;
         good = eg_sweep<1>(c, mb + base, epoch, v, n, code);
@@ -215,74 +231,123 @@ __device__ __forceinline__ bool eg_stage_raw(EgCtx& c, const unsigned long long*
             }
         }
     }
-    eg_st(&c.m->gathering, 0);
     return good;
 }
 
-// ---- one landed slot of a row-major operator: two rows of 4096 weights against the x registers -> two wave-uniform sums
-__device__ __forceinline__ bool eg_slot2(EgCtx& c, int g, const u32x4_t (&xr)[8], float& t0, float& t1) {
-    if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, 0x21)) return false;
+// ---- a landed slot: LDS -> registers (16 x 16 bytes per lane), ring position released at once
+__device__ __forceinline__ bool eg_fetch(EgCtx& c, int g, u32x4_t (&wv)[16], unsigned code) {
+    if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, code)) return false;
     eg_acquire();
     const unsigned char* base = c.ring + (g & 7) * EG_SLOT + c.lane * 16;
-    u32x4_t wv[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) wv[p] = *reinterpret_cast<const u32x4_t*>(base + p * 1024);
     eg_release();                                  // (waits for the reads above)
     eg_st(&c.m->freed[g & 7], (unsigned)g + 1);
+    return true;
+}
+// ---- two rows of 4096 weights (one slot of a row-major operator) against the x registers -> two wave-uniform sums
+__device__ __forceinline__ void eg_rows2(const u32x4_t (&wv)[16], const u32x4_t (&xr)[8], float& t0, float& t1) {
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < 8; ++p) { eg_dot8(wv[p], xr[p], a0); eg_dot8(wv[8 + p], xr[p], a1); }
     t0 = eg_wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
     t1 = eg_wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3]));
+}
+
+enum { EG_OP_QKV = 0, EG_OP_O = 1, EG_OP_GU = 2, EG_OP_LM = 3, EG_OP_DN = 4 };
+
+// Slots consumers 1 / 2 pull into REGISTERS before the operator's input vector exists.  The ring alone is 8 slots = ~4.7 us of stream; the edges of a
+// layer last 4 - 12 us (attention + its all-gather: 11), and whenever the ring is full the weight stream stops.  A consumer wave owns a SIMD (512
+// registers), so consumers 1 and 2 take the FIRST 2 x NP slots of every operator (alternating) into registers as they land -- the leader sweeps the
+// mailbox then, and a slot it owned would block the ring behind it -- and the three share the rest round-robin.
+#ifndef EG_PRE
+#define EG_PRE 1            // qkv, down_proj, lm_head (more than 1 / 2 / 1 sends hipcc into scratch: ~330 registers of phase state stay live whatever the count)
+#endif
+#ifndef EG_PRE_GU
+#define EG_PRE_GU 2         // gate/up: whole pairs (the two activations of one granule)
+#endif
+#ifndef EG_PRE_O
+#define EG_PRE_O 1          // o_proj: live ACROSS the attention code
+#endif
+#define EG_PRE_MAX 4
+template <int OP> struct EgUnit {          // slots per unit (gate/up: the pair of one granule), preloaded slots / units per wave, first round-robin unit
+    static constexpr int US = OP == EG_OP_GU ? 2 : 1, NP = OP == EG_OP_O ? EG_PRE_O : OP == EG_OP_GU ? EG_PRE_GU : EG_PRE, PU = NP / US, F = 2 * PU;
+    static_assert(NP % US == 0 && NP <= EG_PRE_MAX && NP >= 1, "preload counts");
+};
+
+// consumers 1 / 2: preload units (w - 1) + 2 i, i < PU.  Unconditional (the geometry guarantees every operator has at least 2 * EG_PRE_MAX slots): a
+// conditionally defined register array becomes a loop-carried value of the layer loop and is kept live across every phase.
+template <int OP, int NP>
+__device__ __forceinline__ bool eg_preload(EgCtx& c, int g0, u32x4_t (&pre)[NP][16]) {
+    using U = EgUnit<OP>;
+    static_assert(NP == U::NP, "preload registers");
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int slot = ((c.w - 1) + 2 * (i / U::US)) * U::US + (i % U::US);
+        if (!eg_fetch(c, g0 + slot, pre[i], 0x21)) return false;
+    }
     return true;
 }
 
-enum { EG_OP_QKV = 0, EG_OP_O = 1, EG_OP_GU = 2, EG_OP_LM = 3 };
-
-// ---- a row-major operator (K = 4096): the consumer's slots j = w, w + 3, ... of nslots starting at global slot g0 (gate/up: slot PAIRS)
-template <int OP>
-__device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int layer, unsigned seq) {
+// ---- a row-major operator (K = 4096) over nslots slots starting at global slot g0.  LEADER (consumer 0) has no preloaded slots (`pre` unused)
+template <int OP, bool LEADER>
+__device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int layer, unsigned seq, const u32x4_t (*pre)[16]) {
+    using U = EgUnit<OP>;
+    const vcla_engine_args& a = *c.a;
+    const int gpc = (a.g.upc + 1) >> 1;
     if (!eg_wait_ge(&c.m->xin_ready, seq, c.m, c.state, 0x22)) return false;
     eg_acquire();
     u32x4_t xr[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const u32x4_t*>(c.xin + p * 1024 + c.lane * 16);
-    const vcla_engine_args& a = *c.a;
-    if constexpr (OP == EG_OP_GU) {
-        const int gpc = (a.g.upc + 1) >> 1;
-        unsigned long long* mb = eg_mb(c, layer, EG_MB_ACT);
-        const unsigned ep = eg_epoch(c, layer, 4);
-        for (int jp = c.w; jp < gpc; jp += 3) {
-            float g_, u_, v0, v1 = 0.f;
-            if (!eg_slot2(c, g0 + 2 * jp, xr, g_, u_)) return false;
-            v0 = act_silu(g_) * u_;
-            if (2 * jp + 1 < nslots) {
-                if (!eg_slot2(c, g0 + 2 * jp + 1, xr, g_, u_)) return false;
-                v1 = act_silu(g_) * u_;
+    eg_release();                                  // (the copy is complete)
+    eg_st(&c.m->x_taken[c.w], seq);
+    float held = 0.f;                              // gate/up: the first activation of the pair being assembled
+    auto finish = [&](int j, float t0, float t1) {
+        if constexpr (OP == EG_OP_GU) {
+            const float v = act_silu(t0) * t1;
+            const bool last_single = (j & 1) == 0 && j + 1 >= nslots;
+            if ((j & 1) == 0 && !last_single) { held = v; return; }
+            const unsigned d = (j & 1) ? pack_bf2(held, v) : pack_bf2(v, 0.f);
+            if (c.lane == 0) eg_publish(eg_mb(c, layer, EG_MB_ACT), gpc * c.cu + (j >> 1), eg_epoch(c, layer, 4), d);
+        } else if constexpr (OP == EG_OP_QKV) {
+            const int part = j >> 3, jj = j & 7;
+            const int row = part * EG_D + (c.cu >> 3) * EG_HD + (c.cu & 7) * 16 + 2 * jj;
+            if (c.lane == 0) eg_publish(eg_mb(c, layer, EG_MB_QKV), row >> 1, eg_epoch(c, layer, 1), pack_bf2(t0, t1));
+        } else if constexpr (OP == EG_OP_O) {
+            const unsigned d = pack_bf2(t0 + c.m->resid0[2 * j], t1 + c.m->resid0[2 * j + 1]);
+            if (c.lane == 0) {
+                c.m->resid1[2 * j] = eg_lo(d);
+                c.m->resid1[2 * j + 1] = eg_hi(d);
+                eg_publish(eg_mb(c, layer, EG_MB_X1), 8 * c.cu + j, eg_epoch(c, layer, 3), d);
             }
-            if (c.lane == 0) eg_publish(mb, gpc * c.cu + jp, ep, pack_bf2(v0, v1));
+        } else {
+            const int row = 2 * a.g.s_lm * c.cu + 2 * j;
+            if (c.lane == 0) {
+                if (row < a.g.vocab) a.logits[row] = t0;
+                if (row + 1 < a.g.vocab) a.logits[row + 1] = t1;
+            }
         }
-    } else {
-        for (int j = c.w; j < nslots; j += 3) {
+    };
+    if constexpr (!LEADER) {
+#pragma unroll
+        for (int i = 0; i < U::NP; ++i) {
+            const int slot = ((c.w - 1) + 2 * (i / U::US)) * U::US + (i % U::US);
             float t0, t1;
-            if (!eg_slot2(c, g0 + j, xr, t0, t1)) return false;
-            if constexpr (OP == EG_OP_QKV) {
-                const int part = j >> 3, jj = j & 7;
-                const int row = part * EG_D + (c.cu >> 3) * EG_HD + (c.cu & 7) * 16 + 2 * jj;
-                if (c.lane == 0) eg_publish(eg_mb(c, layer, EG_MB_QKV), row >> 1, eg_epoch(c, layer, 1), pack_bf2(t0, t1));
-            } else if constexpr (OP == EG_OP_O) {
-                const unsigned d = pack_bf2(t0 + c.m->resid0[2 * j], t1 + c.m->resid0[2 * j + 1]);
-                if (c.lane == 0) {
-                    c.m->resid1[2 * j] = eg_lo(d);
-                    c.m->resid1[2 * j + 1] = eg_hi(d);
-                    eg_publish(eg_mb(c, layer, EG_MB_X1), 8 * c.cu + j, eg_epoch(c, layer, 3), d);
-                }
-            } else {
-                const int row = 2 * a.g.s_lm * c.cu + 2 * j;
-                if (c.lane == 0) {
-                    if (row < a.g.vocab) a.logits[row] = t0;
-                    if (row + 1 < a.g.vocab) a.logits[row + 1] = t1;
-                }
+            eg_rows2(pre[i], xr, t0, t1);
+            finish(slot, t0, t1);
+        }
+    }
+    for (int u = U::F + c.w; u * U::US < nslots; u += 3) {
+#pragma unroll
+        for (int k = 0; k < U::US; ++k) {
+            const int slot = u * U::US + k;
+            if (slot < nslots) {
+                u32x4_t wv[16];
+                float t0, t1;
+                if (!eg_fetch(c, g0 + slot, wv, 0x21)) return false;
+                eg_rows2(wv, xr, t0, t1);
+                finish(slot, t0, t1);
             }
         }
     }
@@ -292,25 +357,33 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
 }
 
 // ---- down_proj: K-major slots (16 rows x 512 k each); the leader adds the three consumers' partial sums and the residual, publishes x of the next layer
+template <bool LEADER>
 __device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int layer, unsigned seq) {
+    constexpr int NP = EgUnit<EG_OP_DN>::NP;
+    u32x4_t pre[LEADER ? 1 : NP][16];
+    if constexpr (!LEADER) {
+        if (!eg_preload<EG_OP_DN>(c, g0, pre)) return false;
+    }
     if (!eg_wait_ge(&c.m->xin_ready, seq, c.m, c.state, 0x23)) return false;
     eg_acquire();
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int j = c.w; j < nslots; j += 3) {
-        const int g = g0 + j;
-        if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, 0x24)) return false;
-        eg_acquire();
-        const unsigned char* base = c.ring + (g & 7) * EG_SLOT + c.lane * 16;
-        const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
+    if constexpr (!LEADER) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int j = (c.w - 1) + 2 * i;
+            const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(pre[i][r], xk, acc[r]);
+        }
+    }
+    for (int j = 2 * NP + c.w; j < nslots; j += 3) {
         u32x4_t wv[16];
+        if (!eg_fetch(c, g0 + j, wv, 0x24)) return false;
+        const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) wv[p] = *reinterpret_cast<const u32x4_t*>(base + p * 1024);
-        eg_release();
-        eg_st(&c.m->freed[g & 7], (unsigned)g + 1);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = eg_dot8s(wv[i], xk, acc[i]);
+        for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(wv[r], xk, acc[r]);
     }
     float mine = 0.f;
 #pragma unroll
@@ -318,7 +391,7 @@ __device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int la
     if (c.lane < 16) c.m->dpart[c.w][c.lane] = mine;
     eg_release();
     eg_st(&c.m->cons_done[c.w], seq);
-    if (c.w == 0) {
+    if constexpr (LEADER) {
         if (!eg_wait_ge(&c.m->cons_done[1], seq, c.m, c.state, 0x25) || !eg_wait_ge(&c.m->cons_done[2], seq, c.m, c.state, 0x26)) return false;
         eg_acquire();
         const int l = c.lane & 15;
@@ -333,10 +406,13 @@ __device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int la
 }
 
 // ---- attention of one head on this CU's three consumers (RoPE + cache append + single-pass online softmax over the cache; the arithmetic of
-// attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3)
-template <bool MASK>
+// attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3).  U keys per lane group and batch, two batches in flight.
+#ifndef EG_ATT_U
+#define EG_ATT_U 8
+#endif
+template <bool MASK, bool LEADER>
 __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
-    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = 8;
+    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = EG_ATT_U;
     const vcla_engine_args& a = *c.a;
     EgMisc* m = c.m;
     const int h = c.cu >> 3, pos = c.pos, lane = c.lane;
@@ -366,7 +442,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         EG_FD_LOAD(kB, vB, mB, 1)
     }
     const unsigned seq = (unsigned)layer + 1;
-    if (c.w == 0) {
+    if constexpr (LEADER) {
         // q / k / v of the head: 64 granules each (lane t holds elements 2 t, 2 t + 1; the rotate-half partner sits in lane t ^ 32)
         const unsigned long long* mb = eg_mb(c, layer, EG_MB_QKV);
         const unsigned ep = eg_epoch(c, layer, 1);
@@ -379,7 +455,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
             if (__all(good)) break;
             if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
             if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x31); eg_st(&m->gathering, 0); return false; }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
         }
         eg_st(&m->gathering, 0);
         const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
@@ -481,7 +557,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     }
     eg_release();
     eg_st(&m->attn_done[c.w], seq);
-    if (c.w == 0) {
+    if constexpr (LEADER) {
         if (!eg_wait_ge(&m->attn_done[1], seq, m, c.state, 0x33) || !eg_wait_ge(&m->attn_done[2], seq, m, c.state, 0x34)) return false;
         eg_acquire();
         if (lane < 16) {
@@ -508,7 +584,9 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     return true;
 }
 
-template <bool MASK>
+// One consumer wave over the whole step.  LEADER = consumer 0: sweeps the mailboxes, stages every operator's input vector, finishes down_proj,
+// owns no slot among the first 2 * NP of an operator; consumers 1 / 2 pull those into registers while the leader sweeps.
+template <bool MASK, bool LEADER>
 __device__ __forceinline__ void eg_consumer(EgCtx& c) {
     const vcla_engine_args& a = *c.a;
     const vcla_engine_geom& G = a.g;
@@ -520,59 +598,131 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         return eg_wait_ge(&m->cons_done[1], seq, m, c.state, 0x41) && eg_wait_ge(&m->cons_done[2], seq, m, c.state, 0x42);
     };
     auto ready = [&](unsigned seq) { eg_release(); eg_st(&m->xin_ready, seq); };
+    constexpr int NPQ = LEADER ? 1 : EgUnit<EG_OP_QKV>::NP, NPO = LEADER ? 1 : EgUnit<EG_OP_O>::NP, NPG = LEADER ? 1 : EgUnit<EG_OP_GU>::NP;
     for (int l = 0; l < G.n_layers; ++l) {
         const int g0 = l * G.slots_layer;
         const unsigned s0 = (unsigned)l * 4 + 1;
-        if (c.w == 0) {
-            if (l > 0 && !others_done(s0 - 1)) return;
-            if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X), eg_epoch(c, l, 0), a.gamma + (size_t)(2 * l) * EG_D, l == 0)) return;
-            ready(s0);
+        eg_fresh(c);
+        if constexpr (LEADER) eg_stamp(c, l, 0);
+        {
+            u32x4_t pre[NPQ][16];
+            if constexpr (LEADER) {
+                if (l > 0 && !others_done(s0 - 1)) return;
+                if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X), eg_epoch(c, l, 0), a.gamma + (size_t)(2 * l) * EG_D, l == 0)) return;
+                ready(s0);
+                eg_stamp(c, l, 1);
+            } else {
+                if (!eg_preload<EG_OP_QKV>(c, g0, pre)) return;
+            }
+            eg_fresh(c);
+            if (!eg_run_rows<EG_OP_QKV, LEADER>(c, g0, EG_S_QKV, l, s0, pre)) return;
         }
-        if (!eg_run_rows<EG_OP_QKV>(c, g0, EG_S_QKV, l, s0)) return;
-        if (attn_cu && !eg_attention<MASK>(c, l)) return;
-        if (c.w == 0) {
-            if (!others_done(s0)) return;
-            if (!eg_stage_raw(c, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), 2048, 0x12)) return;
-            ready(s0 + 1);
+        if constexpr (LEADER) eg_stamp(c, l, 2);
+        eg_fresh(c);
+        {
+            // o_proj's first slots go into registers BEFORE the attention: the ring then takes the first gate/up slots while the attention runs
+            u32x4_t pre_o[NPO][16];
+            if constexpr (!LEADER) {
+                if (!eg_preload<EG_OP_O>(c, g0 + EG_S_QKV, pre_o)) return;
+            }
+            if (attn_cu && !eg_attention<MASK, LEADER>(c, l)) return;
+            eg_fresh(c);
+            if constexpr (LEADER) {
+                eg_stamp(c, l, 3);
+                if (!others_done(s0)) return;
+                eg_st(&m->gathering, 1);
+                const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), 2048, 0x12, 0, 1);
+                eg_st(&m->gathering, 0);
+                if (!good) return;
+                ready(s0 + 1);
+                eg_stamp(c, l, 4);
+            }
+            eg_fresh(c);
+            if (!eg_run_rows<EG_OP_O, LEADER>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1, pre_o)) return;
         }
-        if (!eg_run_rows<EG_OP_O>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1)) return;
-        if (c.w == 0) {
-            if (!others_done(s0 + 1)) return;
-            if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X1), eg_epoch(c, l, 3), a.gamma + (size_t)(2 * l + 1) * EG_D, false)) return;
-            ready(s0 + 2);
+        if constexpr (LEADER) eg_stamp(c, l, 5);
+        eg_fresh(c);
+        {
+            u32x4_t pre[NPG][16];
+            if constexpr (LEADER) {
+                if (!others_done(s0 + 1)) return;
+                if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X1), eg_epoch(c, l, 3), a.gamma + (size_t)(2 * l + 1) * EG_D, false)) return;
+                ready(s0 + 2);
+                eg_stamp(c, l, 6);
+            } else {
+                if (!eg_preload<EG_OP_GU>(c, g0 + EG_S_QKV + EG_S_O, pre)) return;
+            }
+            eg_fresh(c);
+            if (!eg_run_rows<EG_OP_GU, LEADER>(c, g0 + EG_S_QKV + EG_S_O, G.upc, l, s0 + 2, pre)) return;
         }
-        if (!eg_run_rows<EG_OP_GU>(c, g0 + EG_S_QKV + EG_S_O, G.upc, l, s0 + 2)) return;
-        if (c.w == 0) {
+        if constexpr (LEADER) eg_stamp(c, l, 7);
+        eg_fresh(c);
+        if (a.par_gather) {
+            // all three consumers sweep the activation mailbox (5.5 chunks of 8 KB: 9 - 11 us for one wave), each its chunks w, w + 3 -- once every
+            // one of them has copied gate/up's input out of xin
+            for (int w2 = 0; w2 < 3; ++w2)
+                if (!eg_wait_ge(&m->x_taken[w2], s0 + 2, m, c.state, 0x43)) return;
+            if constexpr (LEADER) eg_st(&m->gathering, 1);
+            const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13, c.w, 3);
+            if constexpr (LEADER) eg_st(&m->gathering, 0);
+            if (!good) return;
+            eg_release();
+            eg_st(&m->gath_done[c.w], s0 + 3);
+            if constexpr (LEADER) {
+                if (!others_done(s0 + 2)) return;
+                if (!eg_wait_ge(&m->gath_done[1], s0 + 3, m, c.state, 0x44) || !eg_wait_ge(&m->gath_done[2], s0 + 3, m, c.state, 0x45)) return;
+                eg_acquire();
+                ready(s0 + 3);
+                eg_stamp(c, l, 8);
+            }
+        } else if constexpr (LEADER) {
             if (!others_done(s0 + 2)) return;
-            if (!eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13)) return;
+            eg_st(&m->gathering, 1);
+            const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13, 0, 1);
+            eg_st(&m->gathering, 0);
+            if (!good) return;
             ready(s0 + 3);
+            eg_stamp(c, l, 8);
         }
-        if (!eg_run_down(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3)) return;
+        eg_fresh(c);
+        if (!eg_run_down<LEADER>(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3)) return;
+        if constexpr (LEADER) eg_stamp(c, l, 9);
     }
     const int L = G.n_layers;
     const unsigned sl = (unsigned)L * 4 + 1;
-    if (c.w == 0) {
-        if (!others_done(sl - 1)) return;
-        if (!eg_stage_norm(c, eg_mb(c, L, EG_MB_X), eg_epoch(c, L, 0), a.gamma + (size_t)(2 * L) * EG_D, false)) return;
-        ready(sl);
+    eg_fresh(c);
+    {
+        u32x4_t pre[NPQ][16];
+        if constexpr (LEADER) {
+            if (!others_done(sl - 1)) return;
+            if (!eg_stage_norm(c, eg_mb(c, L, EG_MB_X), eg_epoch(c, L, 0), a.gamma + (size_t)(2 * L) * EG_D, false)) return;
+            ready(sl);
+        } else {
+            if (!eg_preload<EG_OP_LM>(c, L * G.slots_layer, pre)) return;
+        }
+        eg_fresh(c);
+        if (!eg_run_rows<EG_OP_LM, LEADER>(c, L * G.slots_layer, G.s_lm, L, sl, pre)) return;
     }
-    if (!eg_run_rows<EG_OP_LM>(c, L * G.slots_layer, G.s_lm, L, sl)) return;
     // the launch sequence number moves on once per successful launch (every workgroup read it before its first publish, and this store sits
     // behind the last all-gather, which needed all of them)
-    if (c.cu == 0 && c.w == 0 && c.lane == 0) c.state[0] = (c.eb >> 10) + 1;
+    if (LEADER && c.cu == 0 && c.lane == 0) c.state[0] = (c.eb >> 10) + 1;
 }
 
 __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ring_u, EgMisc* m, unsigned* state, int cu, int lane) {
     const int total = a.g.slots_total;
     const unsigned char* src = a.stream + (size_t)cu * (size_t)total * EG_SLOT + lane * 16;
     unsigned pub = 0;
+    unsigned long long stall = 0, n_stall = 0;
+    const unsigned long long t_begin = a.timeline ? wall_clock64() : 0ull;
     for (int g = 0; g < total; ++g) {
         const int p = g & 7;
         if (g >= 8 && eg_ld(&m->freed[p]) < (unsigned)(g - 7)) {
             // ring full: nothing to issue, so everything issued may as well be published
+            const unsigned long long t0 = a.timeline ? wall_clock64() : 0ull;
             eg_vmcnt<0>();
             if (pub < (unsigned)g) { pub = g; eg_st(&m->filled, pub); }
             if (!eg_wait_ge(&m->freed[p], (unsigned)(g - 7), m, state, 0x01)) break;
+            if (a.timeline) { stall += wall_clock64() - t0; ++n_stall; }
         }
         const unsigned dst = ring_u + p * EG_SLOT;
         const unsigned char* s = src + (size_t)g * EG_SLOT;
@@ -585,6 +735,10 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
     }
     eg_vmcnt<0>();
     eg_st(&m->filled, (unsigned)total);
+    if (a.timeline && lane == 0) {
+        unsigned long long* tl = a.timeline + (size_t)cu * EG_TL_STRIDE + 2040;
+        tl[0] = t_begin; tl[1] = wall_clock64(); tl[2] = stall; tl[3] = n_stall;
+    }
 }
 
 template <bool MASK>
@@ -603,7 +757,7 @@ __global__ __launch_bounds__(256, 1) void decode_engine_kernel(vcla_engine_args 
         EgCtx c;
         c.a = &a; c.ring = eg_lds; c.xin = eg_lds + EG_RING_BYTES; c.m = m; c.state = state;
         c.w = wave - 1; c.lane = lane; c.cu = blockIdx.x; c.eb = (seq << 10) + 1u; c.pos = pos;
-        eg_consumer<MASK>(c);
+        if (wave == 1) eg_consumer<MASK, true>(c); else eg_consumer<MASK, false>(c);
     }
 }
 
@@ -611,6 +765,8 @@ bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_lay
     if (hidden != EG_D || heads != EG_H || inter <= 0 || inter % EG_NCU || n_layers <= 0 || n_layers > 120 || vocab <= 0) return false;
     const int upc = inter / EG_NCU, gpc = (upc + 1) / 2;
     if (EG_NCU * gpc > EG_MB_MAX_ACT) return false;
+    const int s_lm_ = (vocab + 2 * EG_NCU - 1) / (2 * EG_NCU);
+    if (upc < 2 * EG_PRE_MAX || gpc < 2 * EG_PRE_MAX || s_lm_ < 2 * EG_PRE_MAX) return false;     // every operator holds the unconditional register preloads
     g->n_layers = n_layers; g->inter = inter; g->vocab = vocab;
     g->upc = upc; g->s_dn = gpc;
     g->s_lm = (vocab + 2 * EG_NCU - 1) / (2 * EG_NCU);
