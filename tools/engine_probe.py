@@ -29,8 +29,9 @@ def build(layers: int, vocab: int, inter: int):
     return visualcla.VisualCLAModel.from_random(cfg, device="cuda:0", torch_dtype=torch.bfloat16, seed=3)
 
 
-PHASES = ["stage x (gather + RMSNorm)", "qkv slots", "attention (attention CUs only)", "gather attn-out", "o_proj slots", "gather x1 + RMSNorm",
-          "gate/up slots", "gather activations", "down slots + finish"]
+PHASES = ["stage x (gather + RMSNorm)", "qkv slots", "attention (attention CUs only)", "o_proj (slices from the mailbox) + finish", "gather x1 + RMSNorm",
+          "gate/up slots", "down (slices from the mailbox) + finish"]
+STAMPS = [0, 1, 2, 3, 5, 6, 7, 9]
 
 
 def timeline(m, lib, embeds, T, ctx_max, a):
@@ -51,7 +52,7 @@ def timeline(m, lib, embeds, T, ctx_max, a):
         _lib.check(lib.vcla_llama_decode_status(m._ctx, 1, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     del os.environ["VCLA_ENGINE_TL"]
     t = tl.cpu().double() * 0.01      # us
-    st = t[:, :L * 16].view(256, L, 16)[:, :, :10]
+    st = t[:, :L * 16].view(256, L, 16)[:, :, STAMPS]
     cu = torch.arange(256)
     attn = (cu & 7) == ((cu >> 3) & 7)
     d = st[:, :, 1:] - st[:, :, :-1]           # [256, L, 9] phase durations
@@ -60,7 +61,7 @@ def timeline(m, lib, embeds, T, ctx_max, a):
     for k, name in enumerate(PHASES):
         da, do = d[attn][:, lay, k].flatten(), d[~attn][:, lay, k].flatten()
         print(f"  {name:34s} attn-CU {da.median():6.2f} | {da.max():6.2f}    other {do.median():6.2f} | {do.max():6.2f}")
-    per_layer = (st[:, lay, 9] - st[:, lay, 0])
+    per_layer = (st[:, lay, -1] - st[:, lay, 0])
     print(f"  layer, stamp 0 -> 9: median {per_layer.median():.2f} us, max {per_layer.max():.2f} us; whole step (loader begin -> end): "
           f"{(t[:, 2041] - t[:, 2040]).median():.1f} us")
     stall, ns = t[:, 2042], tl.cpu()[:, 2043].double()
@@ -124,11 +125,7 @@ def main():
     kd = (results["0"][2][..., :T + a.steps, :].float() - results["1"][2][..., :T + a.steps, :].float()).abs()
     print(f"K/V cache: max |diff| {kd.max().item():.4f} over the {T + a.steps} rows both paths wrote", flush=True)
     if a.timeline:
-        for pg in (0, 1):
-            os.environ["VCLA_ENGINE_PG"] = str(pg)
-            print(f"--- VCLA_ENGINE_PG={pg} (parallel activation gather)")
-            timeline(m, lib, embeds, T, ctx_max, a)
-        del os.environ["VCLA_ENGINE_PG"]
+        timeline(m, lib, embeds, T, ctx_max, a)
     if a.time > 0:
         for mode in ("0", "1", "0", "1"):
             os.environ["VCLA_ENGINE"] = mode

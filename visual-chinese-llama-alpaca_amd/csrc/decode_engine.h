@@ -9,7 +9,8 @@
 #define EG_HD 128
 #define EG_SLOT 16384          // one ring slot = one LDS-DMA fill = 16 pieces of 1 KiB
 #define EG_S_QKV 24            // slots per CU and layer: 48 rows of wqkv (16 q + 16 k + 16 v rows of ONE head), 2 rows per slot
-#define EG_S_O 8               // 16 rows of wo
+#define EG_S_O 8               // 16 rows of wo, K-major: slot j = the 16 rows x k in [512 j, 512 j + 512)
+#define EG_NRING 9             // LDS ring slots
 // mailboxes (8-byte {tag, two bf16} granules), per layer parity: X | QKV | AO | X1 | ACT
 #define EG_MB_X 0
 #define EG_MB_QKV 2048
@@ -45,7 +46,6 @@ struct vcla_engine_args {
     float scale, eps;
     float* logits;                 // [vocab] fp32
     unsigned long long* mbox;      // EG_WS_BYTES of workspace, zeroed by the caller before the FIRST step of a sequence of launches
-    int par_gather;                // != 0: the three consumers sweep the activation mailbox together (2 chunks each)
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };
 

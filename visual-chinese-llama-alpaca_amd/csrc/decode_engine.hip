@@ -30,8 +30,8 @@ typedef __attribute__((address_space(3))) void* eg_lds_ptr_t;
 typedef __attribute__((address_space(1))) unsigned long long eg_gu64;
 typedef __attribute__((ext_vector_type(2))) __bf16 eg_bf16x2_t;
 
-#define EG_RING_BYTES (8 * EG_SLOT)
-#define EG_XIN_BYTES 22528                 // 11264 bf16: the widest operator input (down_proj in granule order)
+#define EG_RING_BYTES (EG_NRING * EG_SLOT)
+#define EG_XIN_BYTES 8192                  // 4096 bf16: the normalised input vector of qkv / gate-up (o_proj and down_proj read theirs from the mailbox)
 #define EG_MISC_OFF (EG_RING_BYTES + EG_XIN_BYTES)
 #define EG_LDS_BYTES (EG_MISC_OFF + 4096)
 #define EG_SPIN_LDS (1u << 22)             // ~0.4 s of LDS polls
@@ -39,15 +39,13 @@ typedef __attribute__((ext_vector_type(2))) __bf16 eg_bf16x2_t;
 
 struct EgMisc {                            // LDS words shared by the four waves (single writer each)
     unsigned filled;                       // loader: number of slots that have landed (monotonic)
-    unsigned freed[8];                     // consumers: ring position p holds (g + 1) of the last slot released there
+    unsigned freed[EG_NRING];              // consumers: ring position p holds (g + 1) of the last slot released there
     unsigned xin_ready;                    // leader: sequence number of the operator whose input vector is staged
     unsigned cons_done[3];                 // consumer w: sequence number of the last operator it finished
     unsigned attn_ready, attn_done[3];
     unsigned gathering;                    // leader: a mailbox sweep is running (the loader thins itself)
     unsigned fail;
-    unsigned x_taken[3];                   // consumer w: sequence number of the last operator whose input it copied out of xin
-    unsigned gath_done[3];                 // consumer w: sequence number of the last operator whose input chunks it staged
-    unsigned pad_[7];                     // the 32 words above are zeroed at kernel start
+    unsigned pad_[12];                     // the 32 words above are zeroed at kernel start
     float resid0[16], resid1[16];          // the CU's 16 rows of the layer input x / of x + o_proj(...) (bf16 values)
     float dpart[3][16];                    // down_proj: per-consumer partial sums of the CU's 16 rows
     unsigned qpk[64];                      // attention: roped q, packed bf16 pairs
@@ -214,35 +212,16 @@ __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long
     if (from_mem && c.lane < 16) c.m->resid0[c.lane] = bf2f(c.a->x_in[16 * c.cu + c.lane]);
     return true;
 }
-// ---- stage a gathered mailbox as it is (attention output: 2048 granules; SwiGLU activations: 256 * gpc granules), 1024 granules at a time:
-// chunks first, first + step, ...  (the leader alone: 0, 1; all three consumers together: w, 3)
-__device__ __forceinline__ bool eg_stage_raw(EgCtx& c, const unsigned long long* mb, unsigned epoch, int n_gran, unsigned code, int first, int step) {
-    unsigned* xo = reinterpret_cast<unsigned*>(c.xin);
-    bool good = true;
-    for (int base = first * 1024; base < n_gran && good; base += step * 1024) {
-        unsigned v[16];
-        const int n = n_gran - base < 1024 ? n_gran - base : 1024;
-        good = eg_sweep<1>(c, mb + base, epoch, v, n, code);
-        if (good) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int idx = c.lane + 64 * k;
-                if (idx < n) xo[base + idx] = v[k];
-            }
-        }
-    }
-    return good;
-}
-
 // ---- a landed slot: LDS -> registers (16 x 16 bytes per lane), ring position released at once
 __device__ __forceinline__ bool eg_fetch(EgCtx& c, int g, u32x4_t (&wv)[16], unsigned code) {
     if (!eg_wait_ge(&c.m->filled, (unsigned)g + 1, c.m, c.state, code)) return false;
     eg_acquire();
-    const unsigned char* base = c.ring + (g & 7) * EG_SLOT + c.lane * 16;
+    const int rp = g % EG_NRING;
+    const unsigned char* base = c.ring + rp * EG_SLOT + c.lane * 16;
 #pragma unroll
     for (int p = 0; p < 16; ++p) wv[p] = *reinterpret_cast<const u32x4_t*>(base + p * 1024);
     eg_release();                                  // (waits for the reads above)
-    eg_st(&c.m->freed[g & 7], (unsigned)g + 1);
+    eg_st(&c.m->freed[rp], (unsigned)g + 1);
     return true;
 }
 // ---- two rows of 4096 weights (one slot of a row-major operator) against the x registers -> two wave-uniform sums
@@ -300,8 +279,6 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
     u32x4_t xr[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const u32x4_t*>(c.xin + p * 1024 + c.lane * 16);
-    eg_release();                                  // (the copy is complete)
-    eg_st(&c.m->x_taken[c.w], seq);
     float held = 0.f;                              // gate/up: the first activation of the pair being assembled
     auto finish = [&](int j, float t0, float t1) {
         if constexpr (OP == EG_OP_GU) {
@@ -314,13 +291,6 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
             const int part = j >> 3, jj = j & 7;
             const int row = part * EG_D + (c.cu >> 3) * EG_HD + (c.cu & 7) * 16 + 2 * jj;
             if (c.lane == 0) eg_publish(eg_mb(c, layer, EG_MB_QKV), row >> 1, eg_epoch(c, layer, 1), pack_bf2(t0, t1));
-        } else if constexpr (OP == EG_OP_O) {
-            const unsigned d = pack_bf2(t0 + c.m->resid0[2 * j], t1 + c.m->resid0[2 * j + 1]);
-            if (c.lane == 0) {
-                c.m->resid1[2 * j] = eg_lo(d);
-                c.m->resid1[2 * j + 1] = eg_hi(d);
-                eg_publish(eg_mb(c, layer, EG_MB_X1), 8 * c.cu + j, eg_epoch(c, layer, 3), d);
-            }
         } else {
             const int row = 2 * a.g.s_lm * c.cu + 2 * j;
             if (c.lane == 0) {
@@ -356,34 +326,68 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
     return true;
 }
 
-// ---- down_proj: K-major slots (16 rows x 512 k each); the leader adds the three consumers' partial sums and the residual, publishes x of the next layer
-template <bool LEADER>
-__device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int layer, unsigned seq) {
-    constexpr int NP = EgUnit<EG_OP_DN>::NP;
-    u32x4_t pre[LEADER ? 1 : NP][16];
-    if constexpr (!LEADER) {
-        if (!eg_preload<EG_OP_DN>(c, g0, pre)) return false;
+// ---- 256 granules [256 j, 256 j + 256) of a mailbox = the 512 input values slot j of a K-major operator multiplies: lane l takes granules 4 l .. 4 l + 3,
+// i.e. exactly the 8 bf16 its 16-byte weight pieces pair with.  Issue (4 loads per lane) and check are separate so that the next slot's slice is in
+// flight while this one is used.
+struct EgSlice { unsigned long long g[4]; };
+__device__ __forceinline__ void eg_slice_issue(const EgCtx& c, const unsigned long long* mb, int j, EgSlice& s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s.g[q] = eg_peek(mb, 256 * j + 4 * c.lane + q);
+}
+__device__ __forceinline__ bool eg_slice_take(EgCtx& c, const unsigned long long* mb, int j, unsigned epoch, EgSlice& s, u32x4_t& xk, unsigned code) {
+    for (unsigned it = 0;; ++it) {
+        bool good = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) good = good && (unsigned)(s.g[q] >> 32) == epoch;
+        if (__all(good)) break;
+        if ((it & 15) == 15 && eg_ld(&c.m->fail)) return false;
+        if (it > EG_SPIN_GLB) { eg_fail(c.m, c.state, code); return false; }
+        __builtin_amdgcn_s_sleep(2);
+        eg_slice_issue(c, mb, j, s);
     }
-    if (!eg_wait_ge(&c.m->xin_ready, seq, c.m, c.state, 0x23)) return false;
-    eg_acquire();
+    xk = u32x4_t{(unsigned)s.g[0], (unsigned)s.g[1], (unsigned)s.g[2], (unsigned)s.g[3]};
+    return true;
+}
+
+// ---- a K-major operator (o_proj: OP = EG_OP_O, down_proj: EG_OP_DN): slot j = the CU's 16 output rows x 512 inputs.  No gather phase: every wave reads
+// the input slice of its slot straight from the producers' mailbox `mb` (attention output / SwiGLU activations), so the operator starts as soon as the
+// first granules are published.  The leader adds the three consumers' partial sums and the residual, rounds to bf16 and publishes the 16 outputs
+// (o_proj: x1 = x + o_proj(...); down_proj: the next layer's x).
+template <int OP, bool LEADER>
+__device__ __forceinline__ bool eg_run_kmajor(EgCtx& c, int g0, int nslots, int layer, unsigned seq, const unsigned long long* mb, unsigned epoch,
+                                              const u32x4_t (*pre)[16]) {
+    constexpr int NP = EgUnit<OP>::NP;
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // this wave's slots in the order it takes them: consumers 1 / 2 their NP preloaded ones first, then every third of the rest
+    auto slot_of = [&](int t) -> int { return (!LEADER && t < NP) ? (c.w - 1) + 2 * t : 2 * NP + c.w + 3 * (t - (LEADER ? 0 : NP)); };
+    // a mailbox read takes ~2 us under the weight stream and a wave gets a slot every ~1.8 us: three slices in flight
+    EgSlice q0, q1, q2;
+    if (slot_of(0) < nslots) eg_slice_issue(c, mb, slot_of(0), q0);
+    if (slot_of(1) < nslots) eg_slice_issue(c, mb, slot_of(1), q1);
+    if (slot_of(2) < nslots) eg_slice_issue(c, mb, slot_of(2), q2);
+    int t = 0;
     if constexpr (!LEADER) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int j = (c.w - 1) + 2 * i;
-            const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
+        for (int i = 0; i < NP; ++i, ++t) {
+            u32x4_t xk;
+            if (!eg_slice_take(c, mb, slot_of(t), epoch, q0, xk, 0x27)) return false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(pre[i][r], xk, acc[r]);
+            q0 = q1; q1 = q2;
+            if (slot_of(t + 3) < nslots) eg_slice_issue(c, mb, slot_of(t + 3), q2);
         }
     }
-    for (int j = 2 * NP + c.w; j < nslots; j += 3) {
+    for (; slot_of(t) < nslots; ++t) {
         u32x4_t wv[16];
-        if (!eg_fetch(c, g0 + j, wv, 0x24)) return false;
-        const u32x4_t xk = *reinterpret_cast<const u32x4_t*>(c.xin + j * 1024 + c.lane * 16);
+        if (!eg_fetch(c, g0 + slot_of(t), wv, 0x24)) return false;
+        u32x4_t xk;
+        if (!eg_slice_take(c, mb, slot_of(t), epoch, q0, xk, 0x28)) return false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(wv[r], xk, acc[r]);
+        q0 = q1; q1 = q2;
+        if (slot_of(t + 3) < nslots) eg_slice_issue(c, mb, slot_of(t + 3), q2);
     }
     float mine = 0.f;
 #pragma unroll
@@ -395,12 +399,15 @@ __device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int la
         if (!eg_wait_ge(&c.m->cons_done[1], seq, c.m, c.state, 0x25) || !eg_wait_ge(&c.m->cons_done[2], seq, c.m, c.state, 0x26)) return false;
         eg_acquire();
         const int l = c.lane & 15;
-        const float v = (c.m->dpart[0][l] + c.m->dpart[1][l]) + c.m->dpart[2][l] + c.m->resid1[l];
+        const float res = OP == EG_OP_O ? c.m->resid0[l] : c.m->resid1[l];
+        const float v = (c.m->dpart[0][l] + c.m->dpart[1][l]) + c.m->dpart[2][l] + res;
         const float vr = Act<bf16_t>::rnd(v);
         const float nb = __shfl_down(vr, 1, 64);
-        if (c.lane < 16) c.m->resid0[c.lane] = vr;
-        if (c.lane < 16 && (c.lane & 1) == 0)
-            eg_publish(eg_mb(c, layer + 1, EG_MB_X), 8 * c.cu + (c.lane >> 1), eg_epoch(c, layer + 1, 0), pack_bf2(vr, nb));
+        if (c.lane < 16) { if (OP == EG_OP_O) c.m->resid1[c.lane] = vr; else c.m->resid0[c.lane] = vr; }
+        if (c.lane < 16 && (c.lane & 1) == 0) {
+            if (OP == EG_OP_O) eg_publish(eg_mb(c, layer, EG_MB_X1), 8 * c.cu + (c.lane >> 1), eg_epoch(c, layer, 3), pack_bf2(vr, nb));
+            else eg_publish(eg_mb(c, layer + 1, EG_MB_X), 8 * c.cu + (c.lane >> 1), eg_epoch(c, layer + 1, 0), pack_bf2(vr, nb));
+        }
     }
     return true;
 }
@@ -408,7 +415,7 @@ __device__ __forceinline__ bool eg_run_down(EgCtx& c, int g0, int nslots, int la
 // ---- attention of one head on this CU's three consumers (RoPE + cache append + single-pass online softmax over the cache; the arithmetic of
 // attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3).  U keys per lane group and batch, two batches in flight.
 #ifndef EG_ATT_U
-#define EG_ATT_U 8
+#define EG_ATT_U 6            // (8 keys per batch leave the MASK instantiation 8 registers short with o_proj slots held across this code)
 #endif
 template <bool MASK, bool LEADER>
 __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
@@ -592,7 +599,6 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
     const vcla_engine_geom& G = a.g;
     EgMisc* m = c.m;
     const bool attn_cu = (c.cu & 7) == ((c.cu >> 3) & 7);
-    const int gpc = (G.upc + 1) >> 1;
     // the leader may overwrite xin only when the other consumers have finished the operator that reads it
     auto others_done = [&](unsigned seq) -> bool {
         return eg_wait_ge(&m->cons_done[1], seq, m, c.state, 0x41) && eg_wait_ge(&m->cons_done[2], seq, m, c.state, 0x42);
@@ -627,25 +633,15 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
             }
             if (attn_cu && !eg_attention<MASK, LEADER>(c, l)) return;
             eg_fresh(c);
-            if constexpr (LEADER) {
-                eg_stamp(c, l, 3);
-                if (!others_done(s0)) return;
-                eg_st(&m->gathering, 1);
-                const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), 2048, 0x12, 0, 1);
-                eg_st(&m->gathering, 0);
-                if (!good) return;
-                ready(s0 + 1);
-                eg_stamp(c, l, 4);
-            }
-            eg_fresh(c);
-            if (!eg_run_rows<EG_OP_O, LEADER>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1, pre_o)) return;
+            if constexpr (LEADER) eg_stamp(c, l, 3);
+            if (!eg_run_kmajor<EG_OP_O, LEADER>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), pre_o)) return;
         }
         if constexpr (LEADER) eg_stamp(c, l, 5);
         eg_fresh(c);
         {
             u32x4_t pre[NPG][16];
             if constexpr (LEADER) {
-                if (!others_done(s0 + 1)) return;
+                if (!others_done(s0)) return;               // (qkv's readers of xin; o_proj does not touch it)
                 if (!eg_stage_norm(c, eg_mb(c, l, EG_MB_X1), eg_epoch(c, l, 3), a.gamma + (size_t)(2 * l + 1) * EG_D, false)) return;
                 ready(s0 + 2);
                 eg_stamp(c, l, 6);
@@ -657,35 +653,14 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         }
         if constexpr (LEADER) eg_stamp(c, l, 7);
         eg_fresh(c);
-        if (a.par_gather) {
-            // all three consumers sweep the activation mailbox (5.5 chunks of 8 KB: 9 - 11 us for one wave), each its chunks w, w + 3 -- once every
-            // one of them has copied gate/up's input out of xin
-            for (int w2 = 0; w2 < 3; ++w2)
-                if (!eg_wait_ge(&m->x_taken[w2], s0 + 2, m, c.state, 0x43)) return;
-            if constexpr (LEADER) eg_st(&m->gathering, 1);
-            const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13, c.w, 3);
-            if constexpr (LEADER) eg_st(&m->gathering, 0);
-            if (!good) return;
-            eg_release();
-            eg_st(&m->gath_done[c.w], s0 + 3);
-            if constexpr (LEADER) {
-                if (!others_done(s0 + 2)) return;
-                if (!eg_wait_ge(&m->gath_done[1], s0 + 3, m, c.state, 0x44) || !eg_wait_ge(&m->gath_done[2], s0 + 3, m, c.state, 0x45)) return;
-                eg_acquire();
-                ready(s0 + 3);
-                eg_stamp(c, l, 8);
+        {
+            u32x4_t pre[NPQ][16];
+            if constexpr (!LEADER) {
+                if (!eg_preload<EG_OP_DN>(c, g0 + EG_S_QKV + EG_S_O + G.upc, pre)) return;
             }
-        } else if constexpr (LEADER) {
-            if (!others_done(s0 + 2)) return;
-            eg_st(&m->gathering, 1);
-            const bool good = eg_stage_raw(c, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), EG_NCU * gpc, 0x13, 0, 1);
-            eg_st(&m->gathering, 0);
-            if (!good) return;
-            ready(s0 + 3);
-            eg_stamp(c, l, 8);
+            eg_fresh(c);
+            if (!eg_run_kmajor<EG_OP_DN, LEADER>(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), pre)) return;
         }
-        eg_fresh(c);
-        if (!eg_run_down<LEADER>(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3)) return;
         if constexpr (LEADER) eg_stamp(c, l, 9);
     }
     const int L = G.n_layers;
@@ -715,13 +690,13 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
     unsigned long long stall = 0, n_stall = 0;
     const unsigned long long t_begin = a.timeline ? wall_clock64() : 0ull;
     for (int g = 0; g < total; ++g) {
-        const int p = g & 7;
-        if (g >= 8 && eg_ld(&m->freed[p]) < (unsigned)(g - 7)) {
+        const int p = g % EG_NRING;
+        if (g >= EG_NRING && eg_ld(&m->freed[p]) < (unsigned)(g - EG_NRING + 1)) {
             // ring full: nothing to issue, so everything issued may as well be published
             const unsigned long long t0 = a.timeline ? wall_clock64() : 0ull;
             eg_vmcnt<0>();
             if (pub < (unsigned)g) { pub = g; eg_st(&m->filled, pub); }
-            if (!eg_wait_ge(&m->freed[p], (unsigned)(g - 7), m, state, 0x01)) break;
+            if (!eg_wait_ge(&m->freed[p], (unsigned)(g - EG_NRING + 1), m, state, 0x01)) break;
             if (a.timeline) { stall += wall_clock64() - t0; ++n_stall; }
         }
         const unsigned dst = ring_u + p * EG_SLOT;

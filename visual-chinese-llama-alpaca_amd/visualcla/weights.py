@@ -169,8 +169,8 @@ def add_engine_stream(packed: Dict[str, torch.Tensor], hidden: int, heads: int, 
     """`llama.engine.w` [256 CUs][slots_total][8192] bf16 + `llama.engine.g` [2 L + 1][4096] fp32: a THIRD copy of the LLaMA matrices (13.4 GB at
     7B; HBM is 288 GB) in which every CU's share of every operator is one contiguous run of 16-KiB slots in the order the persistent decode step
     consumes them -- its loader wave streams the region front to back without knowing what an operator is.  Per layer and CU c (head h = c // 8,
-    s = c % 8): 24 slots of wqkv (2 rows each: q, k, v rows h*128 + s*16 + 2j), 8 of wo (rows 16c + 2j), upc of wgu (gate row + up row of unit
-    upc*c + j), gpc of wd (K-major: 16 rows x 512 k', k' in granule order, engine_down_kmap); after the layers s_lm slots of lm_head (rows
+    s = c % 8): 24 slots of wqkv (2 rows each: q, k, v rows h*128 + s*16 + 2j), 8 of wo (K-major: rows 16c .. 16c + 15 x 512 k), upc of wgu (gate row + up
+    row of unit upc*c + j), gpc of wd (K-major: 16 rows x 512 k', k' in granule order, engine_down_kmap); after the layers s_lm slots of lm_head (rows
     2 s_lm c + 2j).  Nothing is added when the geometry does not fit (the launch path serves the model)."""
     g = engine_geometry(hidden, heads, inter, vocab, n_layers)
     if g is None or "llama.lm_head" not in packed:
@@ -186,7 +186,7 @@ def add_engine_stream(packed: Dict[str, torch.Tensor], hidden: int, heads: int, 
         blk = stream[:, l * SL:(l + 1) * SL]
         # wqkv [3D, D] -> [part, head, s, j, 2, D] -> [head, s, part, j, 2 D]
         blk[:, 0:24] = packed[d + "wqkv"][:3 * D].view(3, ENGINE_H, 8, 8, 2, D).permute(1, 2, 0, 3, 4, 5).reshape(N, 24, 2 * D)
-        blk[:, 24:32] = packed[d + "wo"][:D].view(N, 8, 2 * D)
+        blk[:, 24:32] = packed[d + "wo"][:D].view(N, 16, 8, 512).permute(0, 2, 1, 3).reshape(N, 8, 16 * 512)     # K-major: slot j = 16 rows x k in [512 j, 512 j + 512)
         # wgu rows come in blocks (16 gate, 16 up): unit u = gate row u and up row u
         blk[:, 32:32 + upc] = packed[d + "wgu"][:2 * inter].view(inter // 16, 2, 16, D).permute(0, 2, 1, 3).reshape(N, upc, 2 * D)
         wd = packed[d + "wd"][:D].index_select(1, ksrc)
