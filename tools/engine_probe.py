@@ -61,6 +61,11 @@ def timeline(m, lib, embeds, T, ctx_max, a):
     for k, name in enumerate(PHASES):
         da, do = d[attn][:, lay, k].flatten(), d[~attn][:, lay, k].flatten()
         print(f"  {name:34s} attn-CU {da.median():6.2f} | {da.max():6.2f}    other {do.median():6.2f} | {do.max():6.2f}")
+    full = t[:, :L * 16].view(256, L, 16)
+    sa = full[attn][:, lay]
+    print(f"  inside the attention (attention CUs, leader wave): qkv done -> q/k/v granules complete {(sa[..., 10] - sa[..., 2]).median():.2f} | RoPE, cache append, LDS "
+          f"{(sa[..., 11] - sa[..., 10]).median():.2f} | scores + PV over the cache {(sa[..., 12] - sa[..., 11]).median():.2f} | wait for the other waves, merge, publish "
+          f"{(sa[..., 3] - sa[..., 12]).median():.2f}")
     per_layer = (st[:, lay, -1] - st[:, lay, 0])
     print(f"  layer, stamp 0 -> 9: median {per_layer.median():.2f} us, max {per_layer.max():.2f} us; whole step (loader begin -> end): "
           f"{(t[:, 2041] - t[:, 2040]).median():.1f} us")

@@ -414,12 +414,10 @@ __device__ __forceinline__ bool eg_run_kmajor(EgCtx& c, int g0, int nslots, int 
 
 // ---- attention of one head on this CU's three consumers (RoPE + cache append + single-pass online softmax over the cache; the arithmetic of
 // attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3).  U keys per lane group and batch, two batches in flight.
-#ifndef EG_ATT_U
-#define EG_ATT_U 6            // (8 keys per batch leave the MASK instantiation 8 registers short with o_proj slots held across this code)
-#endif
+// (8 keys per batch = 192 keys requested before q exists; the MASK instantiation is 8 registers short for that with o_proj slots held across this code: 6)
 template <bool MASK, bool LEADER>
 __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
-    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = EG_ATT_U;
+    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = MASK ? 6 : 8;
     const vcla_engine_args& a = *c.a;
     EgMisc* m = c.m;
     const int h = c.cu >> 3, pos = c.pos, lane = c.lane;
@@ -465,6 +463,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
             __builtin_amdgcn_s_sleep(2);
         }
         eg_st(&m->gathering, 0);
+        eg_stamp(c, layer, 10);
         const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
         const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * (D / 2) + i0);
         const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
@@ -484,6 +483,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         reinterpret_cast<unsigned*>(vbase + (size_t)pos * D)[lane] = vd;
         eg_release();
         eg_st(&m->attn_ready, seq);
+        eg_stamp(c, layer, 11);
     } else {
         if (!eg_wait_ge(&m->attn_ready, seq, m, c.state, 0x32)) return false;
     }
@@ -565,6 +565,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     eg_release();
     eg_st(&m->attn_done[c.w], seq);
     if constexpr (LEADER) {
+        eg_stamp(c, layer, 12);
         if (!eg_wait_ge(&m->attn_done[1], seq, m, c.state, 0x33) || !eg_wait_ge(&m->attn_done[2], seq, m, c.state, 0x34)) return false;
         eg_acquire();
         if (lane < 16) {

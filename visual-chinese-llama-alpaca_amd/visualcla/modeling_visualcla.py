@@ -610,6 +610,14 @@ class VisualCLAModel:
             taps["logits"] = logits
         return logits
 
+    def _check_decode_status(self, B: int, ws: torch.Tensor) -> None:
+        """At B = 1 the decode steps of the bf16 mode are persistent launches whose workgroups wait on each other with BOUNDED spins
+        (csrc/decode_engine.hip); a wait that ran out leaves a code in the workspace and the tokens are garbage -- raise instead of returning
+        them.  One stream synchronisation, at a point where the caller is about to read the tokens anyway."""
+        if B == 1:
+            with torch.cuda.device(self._device):
+                _lib.check(_lib.load().vcla_llama_decode_status(self._ctx, B, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+
     # ------------------------------------------------------------------ forward (parity entry)
     def forward(self, input_ids: Optional[torch.LongTensor] = None, pixel_values: Optional[torch.Tensor] = None,
                 attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.LongTensor] = None,
@@ -874,6 +882,7 @@ class VisualCLAModel:
                     done_at = step
                     break
             toks = out[:min(step, done_at)].t().contiguous()
+            self._check_decode_status(B, ws)
             if eos:
                 is_eos = torch.isin(toks, torch.tensor(eos, device=self._device))
                 after = (is_eos.cumsum(dim=1) - is_eos.int()) > 0
@@ -927,4 +936,5 @@ class VisualCLAModel:
                                                       cache.kv.data_ptr(), ctx_max, _lib.ptr(key_mask),
                                                       step_logits.data_ptr(), None, ws.data_ptr(), ws.numel(), stream))
             logits = step_logits
+        self._check_decode_status(B, ws)
         return generated.contiguous()
