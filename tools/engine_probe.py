@@ -72,6 +72,11 @@ def timeline(m, lib, embeds, T, ctx_max, a):
     stall, ns = t[:, 2042], tl.cpu()[:, 2043].double()
     print(f"  loader: ring-full stalls {ns.median():.0f} per CU, {stall.median():.1f} us stalled per CU (median) of the step; "
           f"slots {a.layers * (32 + a.inter // 256 + (a.inter // 256 + 1) // 2)} + lm_head")
+    SL = 32 + a.inter // 256 + (a.inter // 256 + 1) // 2
+    by_slot = t[:, 1024:1024 + SL].median(dim=0).values / L          # us per layer, median over CUs
+    names = [(0, 24, "qkv"), (24, 32, "o_proj"), (32, 32 + a.inter // 256, "gate/up"), (32 + a.inter // 256, SL, "down")]
+    print("  loader stall by the slot it could not issue (us per layer, median over CUs): " +
+          "; ".join(f"{n} {by_slot[lo:hi].sum():.2f} (worst slot {lo + int(by_slot[lo:hi].argmax())}: {by_slot[lo:hi].max():.2f})" for lo, hi, n in names))
     skew = st[:, lay, 1] - st[:, lay, 1].min(dim=0, keepdim=True).values
     print(f"  skew of 'x staged' over CUs: median {skew.median():.2f} us, max {skew.max():.2f} us")
 
@@ -130,7 +135,11 @@ def main():
     kd = (results["0"][2][..., :T + a.steps, :].float() - results["1"][2][..., :T + a.steps, :].float()).abs()
     print(f"K/V cache: max |diff| {kd.max().item():.4f} over the {T + a.steps} rows both paths wrote", flush=True)
     if a.timeline:
-        timeline(m, lib, embeds, T, ctx_max, a)
+        for thin in (1,):
+            os.environ["VCLA_ENGINE_THIN"] = str(thin)
+            print(f"--- VCLA_ENGINE_THIN={thin}")
+            timeline(m, lib, embeds, T, ctx_max, a)
+        del os.environ["VCLA_ENGINE_THIN"]
     if a.time > 0:
         for mode in ("0", "1", "0", "1"):
             os.environ["VCLA_ENGINE"] = mode

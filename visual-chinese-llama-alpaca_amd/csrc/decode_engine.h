@@ -46,6 +46,7 @@ struct vcla_engine_args {
     float scale, eps;
     float* logits;                 // [vocab] fp32
     unsigned long long* mbox;      // EG_WS_BYTES of workspace, zeroed by the caller before the FIRST step of a sequence of launches
+    int thin;                      // loader keeps ONE fill in flight while its CU sweeps a mailbox (MI355X_MICROARCH.md gather-pass) / 0: never thins
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };
 

@@ -698,14 +698,19 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
             eg_vmcnt<0>();
             if (pub < (unsigned)g) { pub = g; eg_st(&m->filled, pub); }
             if (!eg_wait_ge(&m->freed[p], (unsigned)(g - EG_NRING + 1), m, state, 0x01)) break;
-            if (a.timeline) { stall += wall_clock64() - t0; ++n_stall; }
+            if (a.timeline) {
+                const unsigned long long dt = wall_clock64() - t0;
+                stall += dt; ++n_stall;
+                if (lane == 0 && g < a.g.n_layers * a.g.slots_layer)       // by slot of the layer (an atomic without return: nothing the loader would wait for)
+                    (void)__hip_atomic_fetch_add(a.timeline + (size_t)cu * EG_TL_STRIDE + 1024 + g % a.g.slots_layer, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         const unsigned dst = ring_u + p * EG_SLOT;
         const unsigned char* s = src + (size_t)g * EG_SLOT;
 #pragma unroll
         for (int i = 0; i < 16; ++i) eg_dma16_nt(s + i * 1024, dst + i * 1024);
         unsigned landed;
-        if (eg_ld(&m->gathering)) { eg_vmcnt<16>(); landed = g; }          // thin: at most this fill in flight while the CU sweeps a mailbox
+        if (a.thin && eg_ld(&m->gathering)) { eg_vmcnt<16>(); landed = g; }          // thin: at most this fill in flight while the CU sweeps a mailbox
         else { eg_vmcnt<48>(); landed = g >= 2 ? g - 2 : 0; }              // slots <= g - 3 have landed
         if (landed > pub) { pub = landed; eg_st(&m->filled, pub); }
     }

@@ -912,6 +912,7 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         ea.kv = (bf16_t*)kv_cache; ea.ctx_max = ctx_max; ea.pos0 = pos0; ea.pos_dev = pos_dev; ea.key_mask = key_mask;
         ea.rope_cos = ctx->rope_cos; ea.rope_sin = ctx->rope_sin; ea.scale = 1.0f / sqrtf((float)(D / c.t_heads)); ea.eps = c.t_eps;
         ea.logits = lg; ea.mbox = (unsigned long long*)w.eng;
+        { const char* e_ = getenv("VCLA_ENGINE_THIN"); ea.thin = e_ ? atoi(e_) : 1; }
         if (const char* tl = getenv("VCLA_ENGINE_TL")) ea.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);   // debug: tools/engine_probe.py --timeline
         RUN(vcla_engine_launch(&ea, s));
     } else {
