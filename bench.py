@@ -53,8 +53,10 @@ def parse(argv=None):
     ap.add_argument("--steps-b64", type=int, default=5, help="timed steps of the second workload (configs[2], B = 64 per GPU); 0 = skip it")
     ap.add_argument("--steps-c4", type=int, default=2, help="timed steps of the third workload (BASELINE configs[4] per GPU: fp8 weights, 336 px, "
                     "B = 32 = 256 / 8); 0 = skip it")
-    ap.add_argument("--steps-strong", type=int, default=1, help="timed steps of the fourth workload `strong256`: north_star's scaling claim -- a GLOBAL batch of 256 "
+    ap.add_argument("--steps-strong", type=int, default=2, help="timed steps of the fourth workload `strong256`: north_star's scaling claim -- a GLOBAL batch of 256 "
                     "requests (bf16, 224 px) split evenly over the ranks (B = 256 at N = 1 ... B = 32 at N = 8); 0 = skip it")
+    ap.add_argument("--steps-strong-c4", type=int, default=1, help="timed steps of `strong256_fp8_336`: the same split of a GLOBAL batch of 256 in BASELINE configs[4]'s mode "
+                    "(fp8 weights W8A16, 336 px) -- the N = 1 denominator of configs[4]'s 8-GPU claim; 0 = skip it")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many requests in total, split evenly over the ranks "
                     "(e.g. 256 = north_star's '>= 6x images/sec 1 -> 8 GPUs at batch 256'); replaces --batch, reports scaling = strong")
     ap.add_argument("--prompt-len", type=int, default=128)
@@ -101,7 +103,7 @@ def _event_time(fn, reps: int):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")     # committed rocprofv3 summaries, newest first
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02")     # committed rocprofv3 summaries, newest first
 
 
 def _pmc_traffic(stem: str = "pmc_gemv1p"):
@@ -173,6 +175,64 @@ def gemv_roofline(model, n_rep: int = 20):
     if us_model:     # the same kernel inside the decode graph (rocprofv3 of this command): what the step really pays per launch
         out.update(avg_launch_us_in_model=us_model, frac_in_model=round(alg_bytes / (us_model * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), in_model_source=us_src)
     return _label_static(out)
+
+
+def engine_roofline(model, prompt_len: int = 128, n_steps: int = 96):
+    """Dominant kernel of the B = 1 workload since round 6: decode_engine_kernel (csrc/decode_engine.hip), ONE persistent launch per token that streams
+    every LLaMA linear weight and the lm_head exactly once (algorithmic bytes = those matrices, 13.36 GB at 7B, + the K/V rows of the context, 512 KiB per
+    cached token) -- ~99 % of the decode time.  Measured live: n_steps hipGraph-replayed decode steps between two HIP events on the stream they run on; a
+    step is the engine launch plus the argmax and the token hand-off launch (two sub-10-us kernels), so the figure is the engine's own duration rounded UP.
+    None when the model has no engine stream or VCLA_ENGINE=0 (the launch path then; gemv_roofline describes it)."""
+    import torch
+    from visualcla import _lib
+    if "llama.engine.w" not in model._packed or os.environ.get("VCLA_ENGINE", "1") == "0" or model.fp8_decode:
+        return None
+    lib = _lib.load()
+    t = model.config.text_config
+    D, I, L, V, H = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"], t["vocab_size"], t["num_attention_heads"]
+    dev = model.device
+    ids = torch.randint(3, V - 8, (1, prompt_len), generator=torch.Generator().manual_seed(11)).to(dev)
+    ctx_max = (prompt_len + n_steps + 2 + 63) // 64 * 64
+    embeds, _ = model._embed(ids, None, None)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        cache = model._new_cache(1, ctx_max, _persistent=True)
+        model._prefill(embeds, cache, None, all_logits=False, _persistent=True)
+        ws = model._buf("llama", lib.vcla_llama_workspace_bytes(model._ctx, 1, 1))
+        out = model._typed_buf("gen_out", (n_steps + 1, 1), torch.int64)
+        out[0] = 17
+
+        def loop():
+            model._pos_dev.zero_()
+            _lib.check(lib.vcla_llama_decode_loop(model._ctx, out[0].data_ptr(), 1, prompt_len, model._pos_dev.data_ptr(), n_steps, cache.kv.data_ptr(), ctx_max,
+                                                  None, out[1:].data_ptr(), ws.data_ptr(), ws.numel(), 1, _lib.stream_ptr()))
+        loop()                                   # captures the step graph
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 2
+        e0.record(stream)
+        for _ in range(reps):
+            loop()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        _lib.check(lib.vcla_llama_decode_status(model._ctx, 1, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    sec = e0.elapsed_time(e1) * 1e-3 / (reps * n_steps)
+    w_bytes = 2 * (L * (3 * D * D + D * D + 2 * I * D + D * I) + V * D)
+    kv_bytes = (prompt_len + (n_steps + 1) / 2.0) * KV_BYTES_PER_TOKEN
+    alg = w_bytes + kv_bytes
+    ach = alg / sec / 1e9
+    out_ = {"bound": "hbm", "kernel": "decode_engine_kernel (B=1: the whole decode step -- 32 layers + lm_head -- as ONE persistent launch: per CU an LDS-DMA loader wave "
+            "+ 3 consumer waves, bf16; timed with the step's argmax and token hand-off launches)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": int(alg), "alg_bytes_note": "LLaMA linear weights + lm_head once (%.3f GB) + K/V rows of the mean context (%.1f MB)" % (w_bytes / 1e9, kv_bytes / 1e6),
+            "avg_launch_us": round(sec * 1e6, 1), "launches_timed": reps * n_steps}
+    traffic, src = _pmc_traffic("pmc_engine")
+    if traffic:
+        out_.update(traffic=traffic, traffic_source=src)
+    us_model, us_src = _in_model_us("bench_b1_by_grid.txt", "decode_engine_kernel", 65536)
+    if us_model:
+        out_.update(avg_launch_us_in_model=us_model, frac_in_model=round(alg / (us_model * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), in_model_source=us_src)
+    return _label_static(out_)
 
 
 def batch_decode_gemm_roofline(model, M: int = 64, n_rep: int = 10):
@@ -491,6 +551,8 @@ def plumbing_check(args, rank, world):
                "config": {"workload": "token-pattern stand-in", "global_batch": gB, "parallelism": f"dp{world}"}}
         if strong:
             out["strong256"] = strong
+            if args.steps_strong_c4 > 0:      # the real run times the same split once more in configs[4]'s mode (fp8 W8A16, 336 px)
+                out["strong256_fp8_336"] = dict(strong, steps=args.steps_strong_c4, mode="w8a16")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -625,14 +687,43 @@ def main():
         strong_res = run_workload(256 // world, args.steps_strong, 1)
         strong_res["scaling"] = "strong"
 
+    strong_c4_res = None
+    if args.steps_strong_c4 > 0 and args.batch == 1 and not strong and not args.fp8 and args.image_size == 224 and not args.sample and 256 % world == 0:
+        # configs[4]'s own strong-scaling leg: "fp8 weight path + 336 px, batch 256 on 8 GPUs" -- the global batch of 256 split over the ranks in the SAME
+        # numeric mode `config4` headlines (W8A16: fp8 weights in the decode kernels, bf16 MFMA prefill), so an 8-GPU series has its N = 1 denominator
+        model.set_image_size(336)
+        model.enable_fp8_decode(True, prefill=False, kv_cache=bool(args.fp8_kv))
+        strong_c4_res = run_workload(256 // world, args.steps_strong_c4, 1)
+        strong_c4_res.update(scaling="strong", mode="w8a16")
+        model.enable_fp8_decode(False)
+        model.set_image_size(224)
+
+    def workload_name(B, gB, image_size, fp8, prefill_fp8, kv8, sample, strong_gb=0):
+        """the workload string of a leg, from the flags actually in force, and the BASELINE configs[i] it is (None: a side measurement)"""
+        mode = "bf16" if not fp8 else ("fp8-e4m3 weights (" + ("W8A8: fp8 MFMA prefill, " if prefill_fp8 else "W8A16: bf16 MFMA prefill, ") + "fp8 weights dequantised in registers in the decode steps" +
+                                       (", e4m3 K/V cache" if kv8 else "") + ")")
+        which = None
+        if not sample and args.prompt_len == 128 and args.new_tokens == 128:
+            if not fp8 and image_size == 224:
+                which = 1 if (B == 1 and gB == 1) else 2 if (B == 64 and gB == 64) else 3 if (B == 64 and gB == 512) else None
+            elif fp8 and image_size == 336 and gB == 256:
+                which = 4
+        tag = f"BASELINE configs[{which}]" if which is not None else "not a BASELINE config"
+        if which == 4 and world != 8:
+            tag += f" (its batch of 256 on {world} GPU(s) instead of 8)"
+        if strong_gb and which is None:
+            tag = f"north_star's strong-scaling workload, global batch {strong_gb}" + (" = BASELINE configs[4]'s batch" if fp8 and image_size == 336 and strong_gb == 256 else "")
+        return (f"VisualCLA-7B {mode}, batch={B} image(s)/GPU (global {gB}) at {image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
+                f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if sample else 'greedy'} decode ({tag})")
+
     if rank == 0:
         B = args.batch
-        cfgd = {"workload": (f"VisualCLA-7B bf16, batch={B} image(s)/GPU at {args.image_size}px, prompt T={args.prompt_len} with 64 image tokens, "
-                             f"{args.new_tokens}-token {'sampled (reference default generation config, on-device sampler)' if args.sample else 'greedy'} decode "
-                             f"(BASELINE configs[{1 if B == 1 else 2}]{'; strong scaling: global batch fixed at %d' % args.global_batch if strong else ''}); "
-                             f"second workload config2 = the same at batch=64/GPU (BASELINE configs[2])"),
+        cfgd = {"workload": workload_name(B, main_res["global_batch"], args.image_size, args.fp8, args.fp8, bool(args.fp8_kv) and args.fp8, args.sample,
+                                          args.global_batch if strong else 0) +
+                            ("; second workload config2 = bf16, batch=64/GPU at 224px (BASELINE configs[2])" if b64_res else ""),
                 "global_batch": main_res["global_batch"], "seq_len": args.prompt_len, "new_tokens": args.new_tokens, "image_size": args.image_size,
-                "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"}
+                "parallelism": f"dp{world}", "decode": ("hipGraph" if not args.no_graph else "eager") +
+                ("; B = 1 steps: one persistent launch each (decode_engine_kernel)" if (B == 1 and not args.fp8 and os.environ.get("VCLA_ENGINE", "1") != "0") else "")}
         res = {
             "metric": f"output tokens/sec ({'sampled' if args.sample else 'greedy'}, VisualCLA-7B {args.image_size}px; images/sec alongside)",
             "value": main_res["tokens_per_sec"], "unit": "tokens/s",
@@ -651,11 +742,14 @@ def main():
             "breakdown_ms": main_res.get("breakdown_ms"),
         }
         if b64_res:
-            res["config2"] = dict(b64_res, workload="VisualCLA-7B bf16, batch=64 image(s)/GPU, T=128, 128 greedy tokens (BASELINE configs[2])")
+            res["config2"] = dict(b64_res, workload=workload_name(64, b64_res["global_batch"], 224, False, False, False, False))
         if strong_res:
             res["strong256"] = dict(strong_res, workload=f"VisualCLA-7B bf16, GLOBAL batch 256 split over {world} GPU(s) = {256 // world} image(s)/GPU, 224 px, T=128, "
                                                           f"{args.new_tokens} greedy tokens (north_star's strong-scaling workload: compare images_per_sec / "
                                                           "images_per_sec_prefill of this leg across --gpus 1 / 2 / 4 / 8)")
+        if strong_c4_res:
+            res["strong256_fp8_336"] = dict(strong_c4_res, workload=workload_name(256 // world, 256, 336, True, False, bool(args.fp8_kv), False, 256) +
+                                            " -- the N = 1 ... 8 series of this leg is configs[4]'s scaling curve, in the mode `config4` headlines")
         if c4_res:
             res["config4"] = dict(c4_res, workload="VisualCLA-7B, fp8 weight path, 336 px (577 ViT tokens), batch=32 image(s)/GPU = 256 / 8, T=128, "
                                                    "128 greedy tokens (BASELINE configs[4], one GPU's share); headline mode w8a16, the W8A8 prefill mode under `w8a8`")
@@ -663,7 +757,7 @@ def main():
         b64 = b64_res if b64_res else (main_res if B == 64 else None)
         rl = []
         if not args.fp8:
-            main_rl = gemv_roofline(model) if B == 1 else batch_decode_gemm_roofline(model, min(B, 256))
+            main_rl = (engine_roofline(model, args.prompt_len) or gemv_roofline(model)) if B == 1 else batch_decode_gemm_roofline(model, min(B, 256))
             res["roofline"] = main_rl
             rl.append(main_rl)
             if B == 1 and b64:

@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define VCLA_ABI_VERSION 4
+#define VCLA_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -198,14 +198,12 @@ typedef struct vcla_gemm_args {
        slab-major layout the matrix is stored K-slab by K-slab, [K/64][rows][64]: element (r, k) at ((k/64) * rows + r) * 64 + k % 64, so the
        slab of ANY run of 8 rows is one contiguous 1 KiB.  A_slab [K/64][a_slab_rows][64] bf16 (a_slab_rows >= M) replaces A when set;
        W_slab [K/64][N_pad][64] bf16 replaces W; W_q8_slab [K/64][N_pad][64] e4m3 bytes (16 rows = 1 KiB) replaces W_q8 (w_scale as before).
-       C_slab [N_out/64][c_slab_rows][64] bf16 (N_out % 64 == 0) is an optional SECOND output in the same layout: the next GEMM's A_slab
-       (C may then be NULL).  Ring kernel (11 - 14) and 256x256 kernel (4); visualcla/weights.py:to_slab_major. */
+       Ring kernel (11 - 14) and 256x256 kernel (4); visualcla/weights.py:to_slab_major.  (ABI v4 also declared a slab-major OUTPUT, C_slab /
+       c_slab_rows, that no kernel ever wrote; ABI v5 removed the two fields -- they were the last members, so the struct only got shorter.) */
     const void* A_slab;
     int64_t a_slab_rows;
     const void* W_slab;
     const void* W_q8_slab;
-    void* C_slab;
-    int64_t c_slab_rows;
 } vcla_gemm_args;
 
 /* C = epilogue(A . W^T + bias) (+ residual) */

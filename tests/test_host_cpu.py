@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vcla_version() == 4
+    assert lib.vcla_version() == 5
 
 
 def test_no_gpu_fails_loudly():
@@ -192,7 +192,10 @@ def test_bench_self_spawns_ranks_and_gathers_once():
     assert res["images_per_sec"] > 0 and res["images_per_sec_prefill"] > 0
     s256 = res["strong256"]
     assert s256["global_batch"] == 256 and s256["batch_per_gpu"] == 128 and s256["scaling"] == "strong"
-    assert s256["images_per_sec"] > 0 and s256["images_per_sec_prefill"] > 0
+    assert s256["images_per_sec"] > 0 and s256["images_per_sec_prefill"] > 0 and s256["steps"] >= 2       # (not a single sample)
+    # ... and configs[4]'s own strong-scaling leg (fp8 W8A16, 336 px, the same global batch of 256): its N = 1 run is the denominator of the 8-GPU claim
+    c4s = res["strong256_fp8_336"]
+    assert c4s["global_batch"] == 256 and c4s["batch_per_gpu"] == 128 and c4s["scaling"] == "strong" and c4s["mode"] == "w8a16"
 
 
 def test_synthetic_shards_are_slices_of_the_global_batch():
@@ -743,3 +746,64 @@ def test_generation_config_resolution_follows_transformers_priority():
                 assert w == {"max_length": 20, "min_length": 0}[f]        # "not set" stays None here: visualcla.logits_processors' length rules test for it
                 continue
             assert g == w, (f, passed, kw, g, w)                         # incl. the global defaults (top_k = 50!) and an explicit eos_token_id=None keyword
+
+
+def test_engine_stream_is_every_cu_s_weights_in_consumption_order():
+    """weights.add_engine_stream (the persistent B = 1 decode step's weight twin, csrc/decode_engine.hip): walking CU c's slots exactly as the kernel's
+    consumers do -- qkv two rows per slot, o_proj / down_proj K-major (16 rows x 512 inputs, down_proj's inputs in mailbox-granule order), gate/up one
+    SwiGLU unit per slot, lm_head two rows per slot -- must reproduce the plain matrix products, for an even and an odd number of units per CU."""
+    from visualcla import weights as W
+    D, H, V, L = W.ENGINE_D, W.ENGINE_H, 1100, 1
+    gen = torch.Generator().manual_seed(0)
+
+    def pw(n, k):
+        m = torch.zeros(W.pad_to(n, 128), k, dtype=torch.bfloat16)
+        m[:n] = (torch.randn(n, k, generator=gen) * 0.02).to(torch.bfloat16)
+        return m
+    x = torch.randn(D, generator=gen).bfloat16().float()
+    for inter in (512, 768):                    # 2 and 3 units per CU (the odd one leaves a zero in every CU's last granule)
+        gate, up = pw(inter, D)[:inter], pw(inter, D)[:inter]
+        packed = {"llama.l0.wqkv": pw(3 * D, D), "llama.l0.wo": pw(D, D), "llama.l0.wgu": W._pack_w(W.interleave_gate_up(gate, up), "cpu"),
+                  "llama.l0.wd": pw(D, inter), "llama.lm_head": pw(V, D), "llama.l0.ln1.g": torch.ones(D), "llama.l0.ln2.g": torch.full((D,), 2.0),
+                  "llama.norm.g": torch.full((D,), 3.0)}
+        # (the kernel needs >= 8 slots per operator for its register preloads; the LAYOUT is what is checked here, so build it directly)
+        g = dict(upc=inter // 256, gpc=(inter // 256 + 1) // 2, s_lm=(V + 511) // 512)
+        g.update(slots_layer=32 + g["upc"] + g["gpc"], slots_total=32 + g["upc"] + g["gpc"] + g["s_lm"])
+        orig = W.engine_geometry
+        W.engine_geometry = lambda *a_: g
+        try:
+            W.add_engine_stream(packed, D, H, inter, V, L)
+        finally:
+            W.engine_geometry = orig
+        st = packed["llama.engine.w"].float()
+        assert st.shape == (256, g["slots_total"], 2 * D) and torch.equal(packed["llama.engine.g"][:, 0], torch.tensor([1.0, 2.0, 3.0]))
+        upc, gpc = g["upc"], g["gpc"]
+        cu = torch.arange(256)
+        # qkv: slot j of CU c = rows part*D + (c // 8)*128 + (c % 8)*16 + 2 (j % 8), + 1 with part = j // 8
+        ref = packed["llama.l0.wqkv"][:3 * D].float() @ x
+        got = (st[:, 0:24].reshape(256, 24, 2, D) @ x)
+        j = torch.arange(24)
+        rows = (j[None, :] // 8) * D + (cu[:, None] // 8) * 128 + (cu[:, None] % 8) * 16 + 2 * (j[None, :] % 8)
+        assert torch.allclose(got[..., 0], ref[rows], atol=1e-4) and torch.allclose(got[..., 1], ref[rows + 1], atol=1e-4)
+        # o_proj, K-major: slot j = rows 16 c .. 16 c + 15 against inputs 512 j .. 512 j + 511
+        ref = packed["llama.l0.wo"][:D].float() @ x
+        got = (st[:, 24:32].reshape(256, 8, 16, 512) * x.view(1, 8, 1, 512)).sum(dim=(1, 3))
+        assert torch.allclose(got.reshape(-1), ref, atol=1e-4)
+        # gate/up: slot j of CU c = (gate row, up row) of unit upc * c + j; its activation goes to granule gpc * c + j // 2, half j % 2
+        gu = st[:, 32:32 + upc].reshape(256, upc, 2, D) @ x
+        u = upc * cu[:, None] + torch.arange(upc)[None, :]
+        assert torch.allclose(gu[..., 0], (gate.float() @ x)[u], atol=1e-4) and torch.allclose(gu[..., 1], (up.float() @ x)[u], atol=1e-4)
+        act = torch.zeros(256, gpc, 2)
+        act.view(256, 2 * gpc)[:, :upc] = gu[..., 0] * gu[..., 1]
+        # down_proj, K-major over the mailbox order: slot j multiplies granules 256 j .. 256 j + 255
+        ref = packed["llama.l0.wd"][:D, :inter].float() @ (gate.float() @ x * (up.float() @ x))
+        got = (st[:, 32 + upc:32 + upc + gpc].reshape(256, gpc, 16, 512) * act.reshape(-1).view(1, gpc, 1, 512)).sum(dim=(1, 3))
+        assert torch.allclose(got.reshape(-1), ref, atol=2e-4)
+        assert torch.equal(W.engine_down_kmap(inter).view(256, gpc, 2)[:, :, :][..., 0][:, 0], upc * cu)
+        # lm_head: slot j of CU c = rows 2 s_lm c + 2 j, + 1; rows past the vocabulary are zero
+        lm = (st[:, g["slots_layer"]:].reshape(256, g["s_lm"], 2, D) @ x).reshape(-1)
+        assert torch.allclose(lm[:V], packed["llama.lm_head"][:V].float() @ x, atol=1e-4) and float(lm[V:].abs().max()) == 0.0
+    # the geometry the kernel accepts: LLaMA-7B yes, other widths / too few slots per operator no (those models keep the launch path)
+    assert W.engine_geometry(4096, 32, 11008, 49958, 32) == dict(upc=43, gpc=22, s_lm=98, slots_layer=97, slots_total=32 * 97 + 98)
+    assert W.engine_geometry(5120, 40, 13824, 49958, 40) is None and W.engine_geometry(4096, 32, 11008 + 64, 49958, 32) is None
+    assert W.engine_geometry(4096, 32, 1024, 49958, 2) is None and W.engine_geometry(4096, 32, 11008, 1000, 2) is None

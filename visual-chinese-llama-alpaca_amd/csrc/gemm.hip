@@ -1234,8 +1234,8 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
     VCLA_REQUIRE(dtype == VCLA_F32 || dtype == VCLA_BF16, VCLA_ERR_BAD_DTYPE, "gemm: bad dtype %d", dtype);
     VCLA_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->K % GM_BK == 0, VCLA_ERR_BAD_SHAPE,
                  "gemm: M=%d N=%d K=%d (K must be a positive multiple of %d)", a->M, a->N, a->K, GM_BK);
-    VCLA_REQUIRE((a->A || a->A_frag || a->A_q8 || a->A_slab) && a->W && (a->C || a->C_frag || a->C_slab), VCLA_ERR_BAD_ARG, "gemm: null pointer");
-    VCLA_REQUIRE(!(a->A_slab || a->W_slab || a->W_q8_slab || a->C_slab) || (a->force_kernel >= 11 && a->force_kernel <= 14) || a->force_kernel == 4, VCLA_ERR_BAD_ARG,
+    VCLA_REQUIRE((a->A || a->A_frag || a->A_q8 || a->A_slab) && a->W && (a->C || a->C_frag), VCLA_ERR_BAD_ARG, "gemm: null pointer");
+    VCLA_REQUIRE(!(a->A_slab || a->W_slab || a->W_q8_slab) || (a->force_kernel >= 11 && a->force_kernel <= 14) || a->force_kernel == 4, VCLA_ERR_BAD_ARG,
                  "gemm: slab-major operands belong to the ring kernel (force_kernel 11 - 14) and the 256 x 256 kernel (4)");
     VCLA_REQUIRE(!a->A_slab || (vcla_aligned(a->A_slab, 16) && a->a_slab_rows >= a->M), VCLA_ERR_BAD_ARG, "gemm: A_slab must be 16-byte aligned with a_slab_rows >= M");
     VCLA_REQUIRE(a->epilogue >= VCLA_EPI_NONE && a->epilogue <= VCLA_EPI_SWIGLU, VCLA_ERR_BAD_ARG, "gemm: bad epilogue %d",

@@ -48,7 +48,6 @@ class GemmArgs(C.Structure):
         ("ds_splitk", C.c_int),
         ("ds_raw_partials", C.c_int),
         ("A_slab", C.c_void_p), ("a_slab_rows", C.c_int64), ("W_slab", C.c_void_p), ("W_q8_slab", C.c_void_p),
-        ("C_slab", C.c_void_p), ("c_slab_rows", C.c_int64),
     ]
 
 
@@ -261,7 +260,7 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
          group_rows=0, group_stride=0, row_offset=0, norm_gamma=None, norm_eps=0.0, splitk_ws=None, w_frag=None, w_q8=None, w_q8_frag=None, w_scale=None,
          post_norm_gamma=None, post_norm_eps=0.0, post_norm_out=None, a_frag=None, c_frag=None, m=None,
          c_frag_gamma=None, c_row_ssq=None, a_row_ssq=None, a_norm_eps=0.0, a_q8=None, a_scale=None, ds_splitk=0, ds_raw_partials=False,
-         a_slab=None, w_slab=None, w_q8_slab=None, c_slab=None, k=None):
+         a_slab=None, w_slab=None, w_q8_slab=None, k=None):
     """a [M, K] (fp32 | bf16, row-major), w_packed [N_pad, K] bf16 -> [M, N_out].  a_frag ([K/32, MT, 64, 8], with m = M) selects
     the streaming decode kernel; c_frag (same layout over N_out) receives a fragment-major copy of the output."""
     lib = load()
@@ -287,7 +286,6 @@ def gemm(a, w_packed, n, bias=None, residual=None, epilogue=EPI_NONE, out_f32=Fa
     args.A_q8, args.a_scale = ptr(a_q8), ptr(a_scale)
     args.A_slab, args.a_slab_rows = ptr(a_slab), (a_slab.shape[1] if a_slab is not None else 0)
     args.W_slab, args.W_q8_slab = ptr(w_slab), ptr(w_q8_slab)
-    args.C_slab, args.c_slab_rows = ptr(c_slab), (c_slab.shape[1] if c_slab is not None else 0)
     args.ds_splitk = int(ds_splitk)
     args.ds_raw_partials = int(bool(ds_raw_partials))
     args.c_frag_gamma, args.c_row_ssq, args.a_row_ssq = ptr(c_frag_gamma), ptr(c_row_ssq), ptr(a_row_ssq)

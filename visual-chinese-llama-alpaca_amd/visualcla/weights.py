@@ -148,6 +148,8 @@ def engine_geometry(hidden: int, heads: int, inter: int, vocab: int, n_layers: i
     if ENGINE_NCU * gpc > 5632:
         return None
     s_lm = (vocab + 2 * ENGINE_NCU - 1) // (2 * ENGINE_NCU)
+    if min(upc, gpc, s_lm) < 8:          # every operator must hold the kernel's unconditional register preloads (2 x EG_PRE_MAX slots)
+        return None
     slots_layer = 24 + 8 + upc + gpc
     return dict(upc=upc, gpc=gpc, s_lm=s_lm, slots_layer=slots_layer, slots_total=n_layers * slots_layer + s_lm)
 
