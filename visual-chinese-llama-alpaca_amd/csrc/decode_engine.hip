@@ -164,23 +164,21 @@ __device__ __forceinline__ void eg_stamp(const EgCtx& c, int layer, int k) {
 // ---- sweep NCH x 1024 granules starting at mb (ONE wave): v[k] = data of granule lane + 64 k
 template <int NCH>
 __device__ __forceinline__ bool eg_sweep(EgCtx& c, const unsigned long long* mb, unsigned epoch, unsigned (&v)[NCH * 16], int n_gran, unsigned code) {
+    // all NCH x 16 loads of the lane are in flight together (a pass is latency-bound: ~1 us for 16 loads, not much more for 32)
+    for (unsigned it = 0;; ++it) {
+        bool good = true;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        for (unsigned it = 0;; ++it) {
-            bool good = true;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int idx = c.lane + 64 * (ch * 16 + k);
-                const int idc = idx < n_gran ? idx : n_gran - 1;           // past the end: re-read the last granule (tag checked like any other)
-                const unsigned long long x = eg_peek(mb, idc);
-                v[ch * 16 + k] = (unsigned)x;
-                good = good && (unsigned)(x >> 32) == epoch;
-            }
-            if (__all(good)) break;
-            if ((it & 15) == 15 && eg_ld(&c.m->fail)) return false;
-            if (it > EG_SPIN_GLB) { eg_fail(c.m, c.state, code); return false; }
-            __builtin_amdgcn_s_sleep(8);
+        for (int k = 0; k < NCH * 16; ++k) {
+            const int idx = c.lane + 64 * k;
+            const int idc = idx < n_gran ? idx : n_gran - 1;           // past the end: re-read the last granule (tag checked like any other)
+            const unsigned long long x = eg_peek(mb, idc);
+            v[k] = (unsigned)x;
+            good = good && (unsigned)(x >> 32) == epoch;
         }
+        if (__all(good)) break;
+        if ((it & 15) == 15 && eg_ld(&c.m->fail)) return false;
+        if (it > EG_SPIN_GLB) { eg_fail(c.m, c.state, code); return false; }
+        __builtin_amdgcn_s_sleep(8);
     }
     return true;
 }
