@@ -124,21 +124,26 @@ def test_engine_is_not_used_where_it_does_not_apply(small7b):
 
 def test_engine_steps_match_the_oracle():
     """the engine against the fp32 CPU oracle directly (two layers at the LLaMA-7B widths: the oracle runs in seconds): every decode step's logits within
-    the bf16 bounds of the small configurations (6e-2 max / 1.2e-2 mean), argmax equal wherever the oracle's top-2 margin exceeds twice the bound --
-    with VCLA_ENGINE=0 the launch path must meet the same bounds on the same model (the two forms are interchangeable)"""
+    0.12 max / 0.022 mean of the oracle (measured: 0.056 - 0.081 / 0.0129 - 0.0163; the launch path on the same model and steps: 0.055 - 0.080 / 0.0122 -
+    0.0155), argmax equal wherever the oracle's top-2 margin exceeds twice the max bound, and the engine's mean error within 1.25 x the launch path's --
+    the two forms are interchangeable"""
     from oracle import visualcla_oracle as O
     from tests.helpers import cfg_engine_small, engine_steps_vs_oracle, make_hip_model
     cfg = cfg_engine_small()
     W = O.make_weights(cfg, seed=1)
     m = make_hip_model(cfg, W, torch.bfloat16)
     assert "llama.engine.w" in m._packed
+    got = {}
     try:
         for mode in ("1", "0"):
             os.environ["VCLA_ENGINE"] = mode
             steps = engine_steps_vs_oracle(m, cfg, W, T=33, n_steps=4)
             for s, (mx, mean, a_hip, a_ref, margin) in enumerate(steps):
-                assert mx < 0.06 and mean < 0.012, (mode, s, mx, mean)
-                assert margin < 0.12 or a_hip == a_ref, (mode, s, a_hip, a_ref, margin)
+                assert mx < 0.12 and mean < 0.022, (mode, s, mx, mean)
+                assert margin < 0.24 or a_hip == a_ref, (mode, s, a_hip, a_ref, margin)
+            got[mode] = steps
             print(f"VCLA_ENGINE={mode}: decode-step logits vs fp32 oracle max {max(x[0] for x in steps[1:]):.3e} mean {max(x[1] for x in steps[1:]):.3e}")
     finally:
         os.environ.pop("VCLA_ENGINE", None)
+    for s in range(1, 5):
+        assert got["1"][s][1] <= 1.25 * got["0"][s][1] + 1e-3, (s, got["1"][s], got["0"][s])
