@@ -21,5 +21,7 @@ if counter not in ("FETCH_SIZE", "WRITE_SIZE"):
     sys.exit(0)
 mean_kib = sum(vals) / len(vals)
 corr = 2.0 if counter == "FETCH_SIZE" else 1.0
+alg = {"decode_engine_kernel": "13361 MB of weights + ~69 MB of K/V rows at context ~134 (+ ~1.3 MB of mailbox granules per layer, swept by 256 CUs)"}.get(
+    kernel_filter, "180.4 MB weights (+ KBs of activations / outputs)")
 print(f"{counter}: dispatches={len(vals)} mean={mean_kib:.1f} KiB raw -> {mean_kib * 1024 * corr / 1e6:.1f} MB per launch "
-      f"(x{corr:g} gfx950 correction); algorithmic = 180.4 MB weights (+ KBs of activations / outputs)")
+      f"(x{corr:g} gfx950 correction); algorithmic = {alg}")

@@ -36,11 +36,14 @@ pmc() { # counter workload-script kernel-filter outfile [env]
   rm -rf gpurun_out/pmcx
 }
 rm -f gpurun_out/${tag}_pmc_*.txt
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_engine.py decode_engine_kernel ${tag}_pmc_engine_$(echo $c | tr A-Z a-z).txt; done
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_gemv.py gemv1p_kernel ${tag}_pmc_gemv1p_$(echo $c | tr A-Z a-z).txt; done
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_dstream.py gemm_dstream_kernel ${tag}_pmc_dstream_$(echo $c | tr A-Z a-z).txt; done
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_attn_decode.py attn_decode_flash_kernel ${tag}_pmc_attn_decode_b64_$(echo $c | tr A-Z a-z).txt; done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES; do pmc $c tools/pmc_gemm.py gemm_mfma256_kernel ${tag}_pmc_vit_fc1_mfma.txt VCLA_PMC_SHAPE=vit; done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_vit_attn.py attn_vit_dma_kernel ${tag}_pmc_vit_attn.txt; done
+echo "== engine A/B + timeline (full 7B)"; timeout 900 python tools/engine_probe.py --layers 32 --vocab 49958 --steps 3 --time 64 --timeline 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${tag}_engine_vs_launches.txt
+echo "== bench with the engine off (VCLA_ENGINE=0: the round-5 launch path, same box)"; VCLA_ENGINE=0 timeout 600 python bench.py --steps 3 --warmup 1 --steps-b64 0 --steps-c4 0 --steps-strong 0 --steps-strong-c4 0 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_engine_off.json; cut -c1-300 gpurun_out/${tag}_bench_engine_off.json
 echo "== microbench"
 (python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py dec256 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
 echo "== done"
