@@ -46,6 +46,14 @@ struct vcla_engine_args {
     float scale, eps;
     float* logits;                 // [vocab] fp32
     unsigned long long* mbox;      // EG_WS_BYTES of workspace, zeroed by the caller before the FIRST step of a sequence of launches
+    // greedy tail folded into the launch (decode loops without a sampler; NULL tail_ids_out: off): CU 0 reduces the per-CU maxima of the logits, then does what
+    // vcla_argmax + post_select_kernel did in two more launches -- cur[0] = ids_out[*pos - step_base] = argmax (lowest index among equal maxima), x = embed[argmax], ++*pos
+    int64_t* tail_ids_out;
+    int64_t* tail_cur;
+    const bf16_t* tail_embed;
+    bf16_t* tail_x;
+    int32_t* tail_pos;
+    int tail_step_base;
     int thin;                      // loader keeps ONE fill in flight while its CU sweeps a mailbox (MI355X_MICROARCH.md gather-pass) / 0: never thins
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };

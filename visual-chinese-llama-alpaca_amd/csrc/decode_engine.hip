@@ -48,6 +48,8 @@ struct EgMisc {                            // LDS words shared by the four waves
     unsigned pad_[12];                     // the 32 words above are zeroed at kernel start
     float resid0[16], resid1[16];          // the CU's 16 rows of the layer input x / of x + o_proj(...) (bf16 values)
     float dpart[3][16];                    // down_proj: per-consumer partial sums of the CU's 16 rows
+    float amax_v[3];                       // lm_head: per-consumer maximum of its logits and the lowest row that holds it
+    int amax_i[3];
     unsigned qpk[64];                      // attention: roped q, packed bf16 pairs
     float knew[128], vnew[128];
     float part[3][132];                    // per-consumer (o[128], m, l)
@@ -278,6 +280,8 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
 #pragma unroll
     for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const u32x4_t*>(c.xin + p * 1024 + c.lane * 16);
     float held = 0.f;                              // gate/up: the first activation of the pair being assembled
+    float best = -INFINITY;                        // lm_head: running maximum of this wave's logits (rows increase: strictly greater keeps the lowest index)
+    int best_i = 0x7fffffff;
     auto finish = [&](int j, float t0, float t1) {
         if constexpr (OP == EG_OP_GU) {
             const float v = act_silu(t0) * t1;
@@ -295,6 +299,8 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
                 if (row < a.g.vocab) a.logits[row] = t0;
                 if (row + 1 < a.g.vocab) a.logits[row + 1] = t1;
             }
+            if (row < a.g.vocab && t0 > best) { best = t0; best_i = row; }
+            if (row + 1 < a.g.vocab && t1 > best) { best = t1; best_i = row + 1; }
         }
     };
     if constexpr (!LEADER) {
@@ -319,8 +325,72 @@ __device__ __forceinline__ bool eg_run_rows(EgCtx& c, int g0, int nslots, int la
             }
         }
     }
+    if constexpr (OP == EG_OP_LM) {
+        if (c.lane == 0) { c.m->amax_v[c.w] = best; c.m->amax_i[c.w] = best_i; }
+    }
     eg_release();
     eg_st(&c.m->cons_done[c.w], seq);
+    return true;
+}
+
+// ---- the greedy tail (args.tail_ids_out != NULL): every CU's leader publishes the maximum of its share of the logits, CU 0 picks the winner and does the
+// step's bookkeeping -- what vcla_argmax + post_select_kernel did in two more launches (same tie rule: the lowest index among equal maxima; NaN never wins)
+__device__ __forceinline__ bool eg_greedy_tail(EgCtx& c, int L) {
+    const vcla_engine_args& a = *c.a;
+    EgMisc* m = c.m;
+    float best = m->amax_v[0];
+    int bi = m->amax_i[0];
+#pragma unroll
+    for (int w = 1; w < 3; ++w) {
+        const float v = m->amax_v[w];
+        const int i = m->amax_i[w];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    unsigned long long* mb = eg_mb(c, L, EG_MB_QKV);            // (nobody uses this layer parity's q / k / v mailbox any more)
+    const unsigned ep = eg_epoch(c, L, 5);
+    if (c.lane == 0) {
+        eg_publish(mb, c.cu, ep, __float_as_uint(best));
+        eg_publish(mb, EG_NCU + c.cu, ep, (unsigned)bi);
+    }
+    if (c.cu != 0) return true;
+    float v[4];
+    int ix[4];
+    for (unsigned it = 0;; ++it) {
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long xv = eg_peek(mb, c.lane + 64 * k), xi = eg_peek(mb, EG_NCU + c.lane + 64 * k);
+            v[k] = __uint_as_float((unsigned)xv);
+            ix[k] = (int)(unsigned)xi;
+            good = good && (unsigned)(xv >> 32) == ep && (unsigned)(xi >> 32) == ep;
+        }
+        if (__all(good)) break;
+        if ((it & 15) == 15 && eg_ld(&m->fail)) return false;
+        if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x51); return false; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    best = v[0]; bi = ix[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (v[k] > best || (v[k] == best && ix[k] < bi)) { best = v[k]; bi = ix[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const long long id = bi == 0x7fffffff ? 0 : bi;
+    const int step = c.pos - a.pos0;                            // = *pos_dev at the start of this launch
+    if (c.lane == 0) {
+        a.tail_cur[0] = id;
+        a.tail_ids_out[step - a.tail_step_base] = id;
+        *a.tail_pos = step + 1;
+    }
+    const long long idc = id < a.g.vocab ? id : 0;              // as post_select_kernel: stay in bounds
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.tail_embed + idc * EG_D);
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(a.tail_x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[c.lane + 64 * k] = src[c.lane + 64 * k];
     return true;
 }
 
@@ -677,9 +747,16 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         eg_fresh(c);
         if (!eg_run_rows<EG_OP_LM, LEADER>(c, L * G.slots_layer, G.s_lm, L, sl, pre)) return;
     }
-    // the launch sequence number moves on once per successful launch (every workgroup read it before its first publish, and this store sits
-    // behind the last all-gather, which needed all of them)
-    if (LEADER && c.cu == 0 && c.lane == 0) c.state[0] = (c.eb >> 10) + 1;
+    if constexpr (LEADER) {
+        if (a.tail_ids_out) {
+            if (!others_done(sl)) return;
+            eg_acquire();
+            if (!eg_greedy_tail(c, L)) return;
+        }
+        // the launch sequence number moves on once per successful launch (every workgroup read it before its first publish, and this store sits
+        // behind the last all-gather, which needed all of them)
+        if (c.cu == 0 && c.lane == 0) c.state[0] = (c.eb >> 10) + 1;
+    }
 }
 
 __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ring_u, EgMisc* m, unsigned* state, int cu, int lane) {

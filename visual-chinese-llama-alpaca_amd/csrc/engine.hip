@@ -898,7 +898,7 @@ static bool engine_step_ok(const vcla_ctx* ctx, int B) {
 static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in, int B, int pos0, int32_t* pos_dev,
                             int advance_pos, void* kv_cache, int ctx_max, const int32_t* key_mask, float* logits,
                             int64_t* ids_out, const LlamaWs& w, const vcla_sample_args* samp = nullptr, int n_hist0 = 0,
-                            bool skip_embed = false) {
+                            bool skip_embed = false, int64_t* loop_ids_out = nullptr, int loop_step_base = 0, bool* tail_folded = nullptr) {
     const vcla_model_cfg& c = ctx->c;
     const int dt = c.act_dtype;
     const int D = c.t_hidden;
@@ -912,9 +912,19 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         ea.kv = (bf16_t*)kv_cache; ea.ctx_max = ctx_max; ea.pos0 = pos0; ea.pos_dev = pos_dev; ea.key_mask = key_mask;
         ea.rope_cos = ctx->rope_cos; ea.rope_sin = ctx->rope_sin; ea.scale = 1.0f / sqrtf((float)(D / c.t_heads)); ea.eps = c.t_eps;
         ea.logits = lg; ea.mbox = (unsigned long long*)w.eng;
+        // the decode LOOP without a sampler: argmax, token record, next embedding and position advance happen inside the launch (VCLA_ENGINE_TAIL=0: the
+        // two separate launches, as the loop has done since round 3)
+        const char* tail_s = getenv("VCLA_ENGINE_TAIL");
+        bool fold = loop_ids_out && !samp && ids_out == w.ids && pos_dev && !logits && (tail_s ? atoi(tail_s) != 0 : true);
+        if (fold) {
+            ea.tail_ids_out = loop_ids_out; ea.tail_cur = w.ids; ea.tail_embed = (const bf16_t*)ctx->embed; ea.tail_x = (bf16_t*)w.x;
+            ea.tail_pos = pos_dev; ea.tail_step_base = loop_step_base;
+        }
+        if (tail_folded) *tail_folded = fold;
         { const char* e_ = getenv("VCLA_ENGINE_THIN"); ea.thin = e_ ? atoi(e_) : 1; }
         if (const char* tl = getenv("VCLA_ENGINE_TL")) ea.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);   // debug: tools/engine_probe.py --timeline
         RUN(vcla_engine_launch(&ea, s));
+        if (fold) return VCLA_OK;
     } else {
     for (int l = 0; l < c.t_layers; ++l)   // batched mode: the norms ride on the producing GEMMs, the last one is the final norm
         RUN(llama_layer(ctx, s, ctx->llama[l], w, l, B, 1, pos0, pos_dev, kv_cache, ctx_max, key_mask, l > 0,
@@ -1004,7 +1014,10 @@ extern "C" int vcla_llama_decode_loop_sampled(vcla_ctx* ctx, const int64_t* ids_
     // read from the state words and advance it themselves, so the replayed graph needs no memset node)
     if (engine_step_ok(ctx, B)) VCLA_CHECK_HIP(hipMemsetAsync(w.eng, 0, EG_WS_BYTES, s));
     auto one_step = [&](hipStream_t st) -> int {
-        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0, /*skip_embed=*/true));
+        bool folded = false;
+        RUN(decode_step_impl(ctx, st, w.ids, B, pos0, pos_dev, 0, kv_cache, ctx_max, key_mask, nullptr, w.ids, w, sampling, n_hist0, /*skip_embed=*/true,
+                             ids_out, step_base, &folded));
+        if (folded) return VCLA_OK;            // (the persistent B = 1 step did the token bookkeeping itself)
         if (c.act_dtype == VCLA_BF16 && c.t_hidden % 8 == 0)
             post_select_kernel<bf16_t><<<B, 256, 0, st>>>(w.ids, ids_out, pos_dev, step_base, B, (const bf16_t*)ctx->embed, (bf16_t*)w.x, c.t_hidden, c.t_vocab, w.ticket);
         else if (c.act_dtype == VCLA_BF16)
