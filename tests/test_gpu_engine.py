@@ -63,7 +63,7 @@ def _steps(m, mode, T, n_steps, masked, forced=None):
     return toks, lgs, cache.kv[..., :T + n_steps, :].float().clone()
 
 
-@pytest.mark.parametrize("T,masked", [(160, False), (37, False), (200, True), (1, False)])
+@pytest.mark.parametrize("T,masked", [(160, False), (37, False), (200, True), (1, False), (1011, False), (700, True)])
 def test_engine_steps_match_the_launch_path(small7b, T, masked):
     """logits of every decode step (teacher-forced on the launch path's tokens) and the K / V rows both forms append: within bf16 rounding of each other.
     Bounds: the two forms round the RMSNorm output differently (the engine to bf16 once, the launches keep fp32) and sum in different orders; measured at

@@ -491,7 +491,8 @@ static int gemm(vcla_ctx* ctx, hipStream_t s, const void* A, int64_t lda, const 
         a.A = nullptr; a.A_q8 = ctx->run.q8_ws; a.a_scale = ctx->run.q8s_ws; a.W_q8 = wv->q8; a.w_scale = wv->s8; a.force_kernel = 10;
         return vcla_gemm(&a, ctx->c.act_dtype, s);
     }
-    if (wv && M > 128 && M <= 256 && ctx->run.decode_step && wv->q8 && wv->s8 && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0 &&
+    static const int ring_env = getenv("VCLA_RING") ? atoi(getenv("VCLA_RING")) : 1;      // VCLA_RING=0: the round-4 dispatch everywhere (gemm.hip), also for the fp8 rows below
+    if (ring_env && wv && M > 128 && M <= 256 && ctx->run.decode_step && wv->q8 && wv->s8 && ctx->c.act_dtype == VCLA_BF16 && !norm_gamma && grp_rows == 0 &&
         (epi == VCLA_EPI_NONE || (epi == VCLA_EPI_SWIGLU && !out_f32))) {
         // BASELINE configs[4], decode batches of 129 - 256 sequences (its N = 1 leg, B = 256): the ring kernel stages the fp8 rows as they are and
         // widens them in registers -- the SAME W8A16 function of the dequantised weights the M <= 128 decode kernels compute, whatever the batch

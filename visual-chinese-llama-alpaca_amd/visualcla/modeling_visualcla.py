@@ -740,6 +740,12 @@ class VisualCLAModel:
         if nb > 1 and gc.do_sample:
             raise ValueError("beam search is implemented for do_sample=False (beam SAMPLING draws without replacement from an implementation-defined "
                              "stream upstream); pass do_sample=False with num_beams > 1")
+        if nb > 1 and device_sampling:
+            raise ValueError("device_sampling=True cannot be combined with num_beams > 1: beam search runs HF's bookkeeping on host-driven decode steps")
+        if nb > 1 and getattr(gc, "max_time", None) is not None:
+            # HF applies MaxTimeCriteria inside beam search too; the host bookkeeping here has no early-exit hook for it -- refuse by name rather than drop it
+            raise ValueError("max_time is not implemented for num_beams > 1 (beam search here runs to max_new_tokens or until every beam is finished); "
+                             "use num_beams=1 or leave max_time unset")
         if nb == 1 and (gc.num_return_sequences or 1) != 1 and not gc.do_sample:
             # HF's wording (generation/configuration_utils.py validate): several returned sequences need beams or sampling
             raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {gc.num_return_sequences}).")
