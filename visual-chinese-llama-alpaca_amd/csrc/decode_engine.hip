@@ -185,6 +185,37 @@ __device__ __forceinline__ bool eg_sweep(EgCtx& c, const unsigned long long* mb,
     return true;
 }
 
+// ---- the same sweep with TWO polls in flight, ~0.3 us apart: a mailbox read takes ~1.5 us under the weight stream, so a sweep that arrives before the last
+// producer has published pays up to a whole extra round trip when it polls one pass at a time; staggered passes cut the detection delay to their spacing
+template <int N>
+__device__ __forceinline__ bool eg_sweep_piped(EgCtx& c, const unsigned long long* mb, unsigned epoch, unsigned (&v)[N], unsigned code) {
+    unsigned long long pa[N], pb[N];
+    auto issue = [&](unsigned long long (&d)[N]) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) d[k] = eg_peek(mb, c.lane + 64 * k);
+    };
+    auto take = [&](const unsigned long long (&d)[N]) -> bool {
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) good = good && (unsigned)(d[k] >> 32) == epoch;
+        if (!__all(good)) return false;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (unsigned)d[k];
+        return true;
+    };
+    issue(pa);
+    __builtin_amdgcn_s_sleep(12);
+    issue(pb);
+    for (unsigned it = 0;; ++it) {
+        if (take(pa)) return true;
+        issue(pa);
+        if (take(pb)) return true;
+        issue(pb);
+        if ((it & 7) == 7 && eg_ld(&c.m->fail)) return false;
+        if (it > EG_SPIN_GLB / 2) { eg_fail(c.m, c.state, code); return false; }
+    }
+}
+
 // ---- leader: stage RMSNorm(x) * gamma (bf16) as the next operator's input.  x = the 2048-granule mailbox `mb`, or x_in (plain memory, layer 0)
 __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long* mb, unsigned epoch, const float* gamma, bool from_mem) {
     float2 gm[32];
@@ -197,7 +228,7 @@ __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long
         for (int k = 0; k < 32; ++k) v[k] = xi[c.lane + 64 * k];
     } else {
         eg_st(&c.m->gathering, 1);
-        const bool good = eg_sweep<2>(c, mb, epoch, v, 2048, 0x11);
+        const bool good = eg_sweep_piped<32>(c, mb, epoch, v, 0x11);
         eg_st(&c.m->gathering, 0);
         if (!good) return false;
     }
@@ -403,15 +434,25 @@ __device__ __forceinline__ void eg_slice_issue(const EgCtx& c, const unsigned lo
     for (int q = 0; q < 4; ++q) s.g[q] = eg_peek(mb, 256 * j + 4 * c.lane + q);
 }
 __device__ __forceinline__ bool eg_slice_take(EgCtx& c, const unsigned long long* mb, int j, unsigned epoch, EgSlice& s, u32x4_t& xk, unsigned code) {
-    for (unsigned it = 0;; ++it) {
-        bool good = true;
+    auto good = [&](const EgSlice& d) -> bool {
+        bool g = true;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) good = good && (unsigned)(s.g[q] >> 32) == epoch;
-        if (__all(good)) break;
-        if ((it & 15) == 15 && eg_ld(&c.m->fail)) return false;
-        if (it > EG_SPIN_GLB) { eg_fail(c.m, c.state, code); return false; }
-        __builtin_amdgcn_s_sleep(2);
+        for (int q = 0; q < 4; ++q) g = g && (unsigned)(d.g[q] >> 32) == epoch;
+        return __all(g);
+    };
+    if (!good(s)) {              // the producers are not done: poll with TWO reads in flight, ~0.3 us apart (see eg_sweep_piped)
+        EgSlice t;
+        eg_slice_issue(c, mb, j, t);
+        __builtin_amdgcn_s_sleep(8);
         eg_slice_issue(c, mb, j, s);
+        for (unsigned it = 0;; ++it) {
+            if (good(t)) { s = t; break; }
+            eg_slice_issue(c, mb, j, t);
+            if (good(s)) break;
+            eg_slice_issue(c, mb, j, s);
+            if ((it & 7) == 7 && eg_ld(&c.m->fail)) return false;
+            if (it > EG_SPIN_GLB / 2) { eg_fail(c.m, c.state, code); return false; }
+        }
     }
     xk = u32x4_t{(unsigned)s.g[0], (unsigned)s.g[1], (unsigned)s.g[2], (unsigned)s.g[3]};
     return true;
@@ -521,14 +562,26 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const unsigned ep = eg_epoch(c, layer, 1);
         unsigned qd = 0, kd = 0, vd = 0;
         eg_st(&m->gathering, 1);
-        for (unsigned it = 0;; ++it) {
-            const unsigned long long xq = eg_peek(mb, h * 64 + lane), xk = eg_peek(mb, 2048 + h * 64 + lane), xv = eg_peek(mb, 4096 + h * 64 + lane);
-            qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
-            const bool good = (unsigned)(xq >> 32) == ep && (unsigned)(xk >> 32) == ep && (unsigned)(xv >> 32) == ep;
-            if (__all(good)) break;
-            if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
-            if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x31); eg_st(&m->gathering, 0); return false; }
-            __builtin_amdgcn_s_sleep(2);
+        {   // two polls in flight (see eg_sweep_piped)
+            unsigned long long pa[3], pb[3];
+            auto issue = [&](unsigned long long (&d)[3]) { d[0] = eg_peek(mb, h * 64 + lane); d[1] = eg_peek(mb, 2048 + h * 64 + lane); d[2] = eg_peek(mb, 4096 + h * 64 + lane); };
+            auto take = [&](const unsigned long long (&d)[3]) -> bool {
+                const bool good = (unsigned)(d[0] >> 32) == ep && (unsigned)(d[1] >> 32) == ep && (unsigned)(d[2] >> 32) == ep;
+                if (!__all(good)) return false;
+                qd = (unsigned)d[0]; kd = (unsigned)d[1]; vd = (unsigned)d[2];
+                return true;
+            };
+            issue(pa);
+            __builtin_amdgcn_s_sleep(8);
+            issue(pb);
+            for (unsigned it = 0;; ++it) {
+                if (take(pa)) break;
+                issue(pa);
+                if (take(pb)) break;
+                issue(pb);
+                if ((it & 7) == 7 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
+                if (it > EG_SPIN_GLB / 2) { eg_fail(m, c.state, 0x31); eg_st(&m->gathering, 0); return false; }
+            }
         }
         eg_st(&m->gathering, 0);
         eg_stamp(c, layer, 10);
