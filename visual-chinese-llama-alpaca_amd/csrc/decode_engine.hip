@@ -259,10 +259,11 @@ template <int OP> struct EgUnit {          // slots per unit (gate/up: the pair 
 template <int OP, int NP>
 __device__ __forceinline__ bool eg_preload(EgCtx& c, int g0, u32x4_t (&pre)[NP][16]) {
     using U = EgUnit<OP>;
-    static_assert(NP == U::NP, "preload registers");
+    static_assert(NP == U::PU * U::US, "preload registers");
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int slot = ((c.w - 1) + 2 * (i / U::US)) * U::US + (i % U::US);
+        // K-major operators (no gather phase: the leader is a consumer like the others): slots w, w + 3, ...; row-major ones: consumers 1 / 2 alternate
+        const int slot = (OP == EG_OP_O || OP == EG_OP_DN) ? c.w + 3 * i : ((c.w - 1) + 2 * (i / U::US)) * U::US + (i % U::US);
         if (!eg_fetch(c, g0 + slot, pre[i], 0x21)) return false;
     }
     return true;
@@ -428,24 +429,22 @@ __device__ __forceinline__ bool eg_run_kmajor(EgCtx& c, int g0, int nslots, int 
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // this wave's slots in the order it takes them: consumers 1 / 2 their NP preloaded ones first, then every third of the rest
-    auto slot_of = [&](int t) -> int { return (!LEADER && t < NP) ? (c.w - 1) + 2 * t : 2 * NP + c.w + 3 * (t - (LEADER ? 0 : NP)); };
+    // this wave's slots: w, w + 3, ... -- the first NP of them are already in registers (eg_preload)
+    auto slot_of = [&](int t) -> int { return c.w + 3 * t; };
     // a mailbox read takes ~2 us under the weight stream and a wave gets a slot every ~1.8 us: three slices in flight
     EgSlice q0, q1, q2;
     if (slot_of(0) < nslots) eg_slice_issue(c, mb, slot_of(0), q0);
     if (slot_of(1) < nslots) eg_slice_issue(c, mb, slot_of(1), q1);
     if (slot_of(2) < nslots) eg_slice_issue(c, mb, slot_of(2), q2);
     int t = 0;
-    if constexpr (!LEADER) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i, ++t) {
-            u32x4_t xk;
-            if (!eg_slice_take(c, mb, slot_of(t), epoch, q0, xk, 0x27)) return false;
+    for (int i = 0; i < NP; ++i, ++t) {
+        u32x4_t xk;
+        if (!eg_slice_take(c, mb, slot_of(t), epoch, q0, xk, 0x27)) return false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(pre[i][r], xk, acc[r]);
-            q0 = q1; q1 = q2;
-            if (slot_of(t + 3) < nslots) eg_slice_issue(c, mb, slot_of(t + 3), q2);
-        }
+        for (int r = 0; r < 16; ++r) acc[r] = eg_dot8s(pre[i][r], xk, acc[r]);
+        q0 = q1; q1 = q2;
+        if (slot_of(t + 3) < nslots) eg_slice_issue(c, mb, slot_of(t + 3), q2);
     }
     for (; slot_of(t) < nslots; ++t) {
         u32x4_t wv[16];
@@ -673,7 +672,7 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         return eg_wait_ge(&m->cons_done[1], seq, m, c.state, 0x41) && eg_wait_ge(&m->cons_done[2], seq, m, c.state, 0x42);
     };
     auto ready = [&](unsigned seq) { eg_release(); eg_st(&m->xin_ready, seq); };
-    constexpr int NPQ = LEADER ? 1 : EgUnit<EG_OP_QKV>::NP, NPO = LEADER ? 1 : EgUnit<EG_OP_O>::NP, NPG = LEADER ? 1 : EgUnit<EG_OP_GU>::NP;
+    constexpr int NPQ = LEADER ? 1 : EgUnit<EG_OP_QKV>::NP, NPO = EgUnit<EG_OP_O>::NP, NPG = LEADER ? 1 : EgUnit<EG_OP_GU>::NP, NPD = EgUnit<EG_OP_DN>::NP;
     for (int l = 0; l < G.n_layers; ++l) {
         const int g0 = l * G.slots_layer;
         const unsigned s0 = (unsigned)l * 4 + 1;
@@ -697,9 +696,7 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         {
             // o_proj's first slots go into registers BEFORE the attention: the ring then takes the first gate/up slots while the attention runs
             u32x4_t pre_o[NPO][16];
-            if constexpr (!LEADER) {
-                if (!eg_preload<EG_OP_O>(c, g0 + EG_S_QKV, pre_o)) return;
-            }
+            if (!eg_preload<EG_OP_O>(c, g0 + EG_S_QKV, pre_o)) return;
             if (attn_cu && !eg_attention<MASK, LEADER>(c, l)) return;
             eg_fresh(c);
             if constexpr (LEADER) eg_stamp(c, l, 3);
@@ -723,10 +720,8 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
         if constexpr (LEADER) eg_stamp(c, l, 7);
         eg_fresh(c);
         {
-            u32x4_t pre[NPQ][16];
-            if constexpr (!LEADER) {
-                if (!eg_preload<EG_OP_DN>(c, g0 + EG_S_QKV + EG_S_O + G.upc, pre)) return;
-            }
+            u32x4_t pre[NPD][16];
+            if (!eg_preload<EG_OP_DN>(c, g0 + EG_S_QKV + EG_S_O + G.upc, pre)) return;
             eg_fresh(c);
             if (!eg_run_kmajor<EG_OP_DN, LEADER>(c, g0 + EG_S_QKV + EG_S_O + G.upc, G.s_dn, l, s0 + 3, eg_mb(c, l, EG_MB_ACT), eg_epoch(c, l, 4), pre)) return;
         }
