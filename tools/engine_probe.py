@@ -141,12 +141,7 @@ def main():
             timeline(m, lib, embeds, T, ctx_max, a)
         del os.environ["VCLA_ENGINE_THIN"]
     if a.time > 0:
-        variants = [("0", {}), ("1", {})] + [("1", {"VCLA_ENGINE_QDELAY": str(q), "VCLA_ENGINE_XDELAY": str(x)}) for q, x in ((8, 0), (14, 0), (20, 0), (0, 6), (0, 12), (14, 8))] + [("1", {})]
-        for mode, extra in variants:
-            for k_ in ("VCLA_ENGINE_QDELAY", "VCLA_ENGINE_XDELAY"):
-                os.environ.pop(k_, None)
-            os.environ.update(extra)
-            print("   ", extra, end=" ")
+        for mode in ("0", "1", "0", "1"):
             os.environ["VCLA_ENGINE"] = mode
             cache = m._new_cache(1, ctx_max, _persistent=True)
             key_mask = m._key_mask(None, 1, T, ctx_max)

@@ -54,7 +54,6 @@ struct vcla_engine_args {
     bf16_t* tail_x;
     int32_t* tail_pos;
     int tail_step_base;
-    int qkv_delay, x_delay;        // experiment: 0.1-us units the attention leader / the x sweeps wait before their FIRST mailbox pass
     int thin;                      // loader keeps ONE fill in flight while its CU sweeps a mailbox (MI355X_MICROARCH.md gather-pass) / 0: never thins
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };

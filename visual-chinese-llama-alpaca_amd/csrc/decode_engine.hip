@@ -197,7 +197,6 @@ __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long
         for (int k = 0; k < 32; ++k) v[k] = xi[c.lane + 64 * k];
     } else {
         eg_st(&c.m->gathering, 1);
-        for (int z = 0; z < c.a->x_delay; ++z) __builtin_amdgcn_s_sleep(4);
         const bool good = eg_sweep<2>(c, mb, epoch, v, 2048, 0x11);
         eg_st(&c.m->gathering, 0);
         if (!good) return false;
@@ -521,7 +520,6 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const unsigned ep = eg_epoch(c, layer, 1);
         unsigned qd = 0, kd = 0, vd = 0;
         eg_st(&m->gathering, 1);
-        for (int z = 0; z < a.qkv_delay; ++z) __builtin_amdgcn_s_sleep(4);
         for (unsigned it = 0;; ++it) {
             const unsigned long long xq = eg_peek(mb, h * 64 + lane), xk = eg_peek(mb, 2048 + h * 64 + lane), xv = eg_peek(mb, 4096 + h * 64 + lane);
             qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
