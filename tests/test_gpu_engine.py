@@ -147,3 +147,26 @@ def test_engine_steps_match_the_oracle():
         os.environ.pop("VCLA_ENGINE", None)
     for s in range(1, 5):
         assert got["1"][s][1] <= 1.25 * got["0"][s][1] + 1e-3, (s, got["1"][s], got["0"][s])
+
+
+def test_a_workgroup_that_never_publishes_is_a_status_code_not_a_hang(small7b):
+    """every wait inside the persistent launch is bounded: with one workgroup's consumers gone (test hook VCLA_ENGINE_FAULT=1) the launch must drain within
+    about a second, `vcla_llama_decode_status` must name a wait site, `generate()` must raise instead of returning tokens -- and the next call must work"""
+    import time
+    from visualcla import _lib
+    m = small7b
+    os.environ["VCLA_ENGINE"] = "1"
+    V = m.config.text_config["vocab_size"]
+    ids = torch.randint(3, V - 8, (1, 33), generator=torch.Generator().manual_seed(2)).to(m.device)
+    kw = dict(input_ids=ids, max_new_tokens=3, do_sample=False, eos_token_id=None, use_graph=False)
+    good = m.generate(**kw)
+    os.environ["VCLA_ENGINE_FAULT"] = "1"
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(_lib.VclaError, match="timed out"):
+            m.generate(**kw)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 20.0
+    finally:
+        os.environ.pop("VCLA_ENGINE_FAULT", None)
+    assert torch.equal(m.generate(**kw), good)

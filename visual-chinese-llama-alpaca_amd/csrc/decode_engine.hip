@@ -808,6 +808,7 @@ __global__ __launch_bounds__(256, 1) void decode_engine_kernel(vcla_engine_args 
         EgCtx c;
         c.a = &a; c.ring = eg_lds; c.xin = eg_lds + EG_RING_BYTES; c.m = m; c.state = state;
         c.w = wave - 1; c.lane = lane; c.cu = blockIdx.x; c.eb = (seq << 10) + 1u; c.pos = pos;
+        if (a.fault && blockIdx.x == 7) return;                  // test hook: a workgroup that never publishes (tests/test_gpu_engine.py)
         if (wave == 1) eg_consumer<MASK, true>(c); else eg_consumer<MASK, false>(c);
     }
 }
