@@ -312,7 +312,7 @@ def test_edge_beam_search_matches_reference(dtype, golden_dir):
     """generate(num_beams > 1) (round 4 raised; the reference forwards it to HF generate, modeling_visualcla.py:382-391): the reference's own outputs for
     (a) 3 beams without an eos id, (b) 3 beams with an eos id the beams do produce (hypotheses finish early, the length penalty ranks them, the returned
     row is filled with the eos id), (c) 4 beams, early_stopping=True, length_penalty 0.6, two returned hypotheses per prompt.  fp32 mode: the ids of the
-    fixture; bf16 mode: the same calls run (every decode step goes through the B * num_beams-row kernels, the cache rows are gathered between steps)
+    fixture; bf16 mode: the same calls run (every decode step goes through the B * num_beams-row kernels, the prompt is prefilled once and broadcast to its beams, the generated cache positions are gathered between steps)
     and return well-formed hypotheses."""
     e = _edge(golden_dir, "beams")
     cfg, m, px, ids, mask = _edge_model(dtype)

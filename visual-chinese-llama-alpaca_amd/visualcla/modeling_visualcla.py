@@ -773,10 +773,12 @@ class VisualCLAModel:
         return toks
 
     def _beam_generate(self, gc, embeds, am, T, n_new, ctx_max, eos, logits_processor, stopping_criteria, prefix_fn=None):
-        """num_beams > 1 (the reference forwards it to HF generate, modeling_visualcla.py:382-391).  As HF does with `inputs_embeds`, every prompt's
-        spliced embeddings are repeated num_beams times AFTER the vision stack ran once per image; the prefill and every decode step run on the
-        B * num_beams rows through the same kernels as any batch of that size (host-driven steps), the K / V cache rows are re-ordered to the
-        surviving beams between steps (a row gather on the cache tensor: data movement, like HF's `reorder_cache`), and the beam bookkeeping is
+        """num_beams > 1 (the reference forwards it to HF generate, modeling_visualcla.py:382-391).  HF repeats every prompt num_beams times and prefills all
+        B * num_beams rows; the beams of a prompt are identical until the first step, so here the vision stack and the PREFILL run once per prompt (B rows)
+        and the prompt's K / V rows and first logits are broadcast to its beams (one copy of T positions).  Decode steps run on the B * num_beams rows through
+        the same kernels as any batch of that size (host-driven steps).  Between steps the cache rows follow the surviving beams (HF's `reorder_cache`): a
+        beam's parent is always a beam of the SAME prompt (beam_search.py: beam_rows = group offset + index within the group), whose first T positions are
+        that prompt's -- only the generated positions [T, pos) are gathered, O(generated) bytes per step instead of O(context).  Bookkeeping:
         visualcla/beam_search.py.  Returns [B * num_return_sequences, n] new tokens."""
         from .beam_search import beam_search
         lib = _lib.load()
@@ -784,10 +786,12 @@ class VisualCLAModel:
         nb = int(gc.num_beams)
         B = embeds.shape[0]
         rows = B * nb
-        x = embeds.repeat_interleave(nb, dim=0).contiguous()
+        cache1 = self._new_cache(B, ctx_max)
+        first = self._prefill(embeds, cache1, self._key_mask(am, B, T, ctx_max), all_logits=False).repeat_interleave(nb, dim=0)
         cache = self._new_cache(rows, ctx_max)
+        cache.kv.view(cache.kv.shape[0], 2, B, nb, *cache.kv.shape[3:])[:, :, :, :, :, :T].copy_(cache1.kv[:, :, :, None, :, :T])
+        del cache1
         key_mask = self._key_mask(None if am is None else am.repeat_interleave(nb, dim=0), rows, T, ctx_max)
-        first = self._prefill(x, cache, key_mask, all_logits=False)
         ws = self._buf("llama", lib.vcla_llama_workspace_bytes(self._ctx, rows, 1))
         step_logits = torch.empty(rows, t["vocab_size"], dtype=torch.float32, device=self._device)
         ident = torch.arange(rows, device=self._device)
@@ -795,8 +799,8 @@ class VisualCLAModel:
 
         def step(tokens, beam_rows):
             pos = state["pos"]
-            if not torch.equal(beam_rows, ident):        # the filled prefix of every cache row follows its beam
-                filled = cache.kv[:, :, :, :, :pos, :]
+            if pos > T and not torch.equal(beam_rows, ident):        # the generated positions of every cache row follow its beam
+                filled = cache.kv[:, :, :, :, T:pos, :]
                 filled.copy_(filled.index_select(2, beam_rows))
             with torch.cuda.device(self._device):
                 _lib.check(lib.vcla_llama_decode_step(self._ctx, tokens.contiguous().data_ptr(), rows, pos, None, 0, cache.kv.data_ptr(), ctx_max,
