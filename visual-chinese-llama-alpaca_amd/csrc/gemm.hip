@@ -1297,6 +1297,11 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             // (gemm_ring.hip) -- full K per tile, no split-K partials.  VCLA_RING=0: the round-4 dispatch (128 x 128 tiles + K slices).
             static const int ring_env = getenv("VCLA_RING") ? atoi(getenv("VCLA_RING")) : 1;
             if (ring_env && a->M <= 256 && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && a->c_group_rows <= 0) kernel = 11;
+            // ONE image through the ViT (257 rows, K = 1024: qkv / out / fc1): 72 - 96 tiles of 128 x 128 needed K slices + a reduce launch to fill the chip; 64 x 64
+            // (128 x 96) ring tiles over the full K fill it in one launch with the bias / GELU / residual in the tile's epilogue.  Graph-replayed, rotating weights,
+            // M = 257: qkv 25.4 -> 14.0 us, out 17.8 -> 13.5, fc1 28.0 -> 18.0; fc2 (K = 4096) stays on the K slices (24.2 vs 26.2).  VCLA_RING_VIT=0: off.
+            static const int ring_vit_env = getenv("VCLA_RING_VIT") ? atoi(getenv("VCLA_RING_VIT")) : 1;
+            if (ring_env && ring_vit_env && a->M <= 320 && a->K <= 2048 && !a->out_f32 && a->epilogue != VCLA_EPI_SWIGLU && a->c_group_rows <= 0 && a->A && !a->W_q8) kernel = 11;
         }
     }
     VCLA_REQUIRE(kernel >= 1 && kernel <= 14, VCLA_ERR_BAD_ARG, "gemm: bad force_kernel %d", a->force_kernel);
@@ -1307,9 +1312,9 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
         VCLA_REQUIRE(a->C && !a->C_frag && !a->A_frag && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq, VCLA_ERR_BAD_ARG,
                      "gemm: the fp8 MFMA kernel writes a row-major C and takes no fused norms");
     } else if (kernel >= 11) {
-        VCLA_REQUIRE(dtype == VCLA_BF16 && (a->A || a->A_slab) && a->C && (a->epilogue == VCLA_EPI_NONE || (a->epilogue == VCLA_EPI_SWIGLU && !a->out_f32)) && !a->C_frag &&
+        VCLA_REQUIRE(dtype == VCLA_BF16 && (a->A || a->A_slab) && a->C && (a->epilogue == VCLA_EPI_NONE || !a->out_f32) && !a->C_frag &&
                          !a->A_frag && !a->A_q8 && !a->a_scale && !a->norm_gamma && !a->c_row_ssq && !a->a_row_ssq && !a->c_frag_gamma, VCLA_ERR_BAD_ARG,
-                     "gemm: the ring kernel takes a row-major bf16 A, epilogue NONE (bf16 / fp32 C) or SWIGLU (bf16 C), no fused norms");
+                     "gemm: the ring kernel takes a row-major bf16 A, epilogue NONE (bf16 / fp32 C) or SWIGLU / a GELU (bf16 C), no fused norms");
         VCLA_REQUIRE(!(a->W_q8 || a->W_q8_slab) || (a->w_scale && vcla_aligned(a->W_q8, 16) && vcla_aligned(a->W_q8_slab, 16)), VCLA_ERR_BAD_ARG,
                      "gemm: the ring kernel's fp8 weights need W_q8 or W_q8_slab (16-byte aligned) + w_scale");
         VCLA_REQUIRE(!a->W_slab || vcla_aligned(a->W_slab, 16), VCLA_ERR_BAD_ARG, "gemm: W_slab must be 16-byte aligned");

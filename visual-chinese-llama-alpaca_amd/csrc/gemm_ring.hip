@@ -289,5 +289,8 @@ int vcla_gemm_ring_launch(const vcla_gemm_args* a, hipStream_t s) {
         if (a->out_f32) return w8 ? launch_ring<VCLA_EPI_NONE, float, true>(a, s) : launch_ring<VCLA_EPI_NONE, float, false>(a, s);     // lm_head: fp32 logits
         return w8 ? launch_ring<VCLA_EPI_NONE, bf16_t, true>(a, s) : launch_ring<VCLA_EPI_NONE, bf16_t, false>(a, s);
     }
-    return vcla_fail(VCLA_ERR_BAD_ARG, "gemm: the ring kernel implements epilogues NONE (bf16 / fp32 output) and SWIGLU (bf16 output), got %d", a->epilogue);
+    // one image through the ViT / the resampler (257 or 65 rows, K = 1024): bias + activation in the tile's own epilogue instead of K slices + a reduce launch
+    if (!w8 && !a->out_f32 && a->epilogue == VCLA_EPI_QUICK_GELU) return launch_ring<VCLA_EPI_QUICK_GELU, bf16_t, false>(a, s);
+    if (!w8 && !a->out_f32 && a->epilogue == VCLA_EPI_GELU_ERF) return launch_ring<VCLA_EPI_GELU_ERF, bf16_t, false>(a, s);
+    return vcla_fail(VCLA_ERR_BAD_ARG, "gemm: the ring kernel implements epilogues NONE (bf16 / fp32 output), SWIGLU (bf16 output) and the two GELUs (bf16 weights and output), got %d", a->epilogue);
 }
