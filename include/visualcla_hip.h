@@ -35,6 +35,7 @@
  *                           hf:llama/modeling_llama.py:191-214; modeling_visual_resampler.py:213-253
  *   vcla_image_preprocess_batch   the same call sites, N same-sized images per launch pair
  *   vcla_image_preprocess   (next row N1) CLIPImageProcessor.__call__ as invoked at models/visualcla/modeling_utils.py:150-152
+ *   vcla_check_request      the request checks in front of them: image-slot shape modeling_visualcla.py:296-302 / :362-367, ids / labels in range, mask shape
  *   vcla_embed_splice       embed_tokens + image splice modeling_visualcla.py:280,292-305 / :346,358-370
  *   vcla_rope_kv_append     apply_rotary_pos_emb + cache update hf:llama/modeling_llama.py:130-160,255-259
  *   vcla_attn_decode_fused  the decode-step instance of LlamaAttention.forward hf:llama/modeling_llama.py:217-281
@@ -266,6 +267,17 @@ int vcla_image_preprocess_batch(const uint8_t* imgs, int N, int H, int W, uint8_
                                 const int32_t* h_cnt, const int32_t* h_k, int h_kmax, const int32_t* v_lo, const int32_t* v_cnt,
                                 const int32_t* v_k, int v_kmax, double rescale, const float* mean3, const float* std3, void* out,
                                 int dtype, void* stream);
+
+/* Every data-dependent validation of a request (ids [B, T] int64) in ONE launch; the caller copies the five flags back and raises the reference's
+   errors (modeling_visualcla.py:296-302 forward, :362-367 generate).  flags (int32[5], zeroed here): [0] an id outside [0, vocab); [1] q_tokens > 0 and
+   a row whose first start_id (<img>) is not followed by q_tokens fillers and end_id (</img>) inside the row -- rows without start_id (need_tok: or without
+   tok_id, as `forward` asks) carry no image and pass; [2] mask has a zero; [3] mask has a visible position after a masked one that follows a visible
+   one (a hole rather than padding at either end; mask_prefix_visible: as if visible columns preceded the mask, the image_at_head placement); [4] a label
+   outside [0, vocab) other than -100.  img_pos[b] (int32, may be NULL; written when q_tokens > 0) = position of the row's first start_id, -1 for rows
+   without an image.  mask [B, Tm] / labels [B, Tl] int64 or NULL. */
+int vcla_check_request(const int64_t* ids, int B, int T, int vocab, int q_tokens, int64_t start_id, int64_t end_id, int64_t tok_id, int need_tok,
+                       const int64_t* mask, int Tm, int mask_prefix_visible, const int64_t* labels, int Tl, int32_t* img_pos, int32_t* flags,
+                       void* stream);
 
 /* out[b, t] = table[ids[b, t]], except rows img_pos[b]+1 .. img_pos[b]+Q which take image_embeds[b, :]
    (img_pos[b] < 0: no image in that sample).  table is bf16 [V, D]. */

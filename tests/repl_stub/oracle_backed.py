@@ -58,6 +58,35 @@ class OracleBackedModel(M.VisualCLAModel):
                            max_position_embeddings=t["max_position_embeddings"]),
             img_start_token_id=tk.img_start_token_id, img_end_token_id=tk.img_end_token_id, img_token_id=tk.img_token_id)
 
+    def _request_flags(self, ids, am64, lab, q_slot, special, need_tok, prefix_visible):
+        """the five answers of `vcla_check_request` (include/visualcla_hip.h) in plain tensor algebra: what the CPU tests of `_check_request` run on, and the
+        checker tests/test_gpu_model.py holds the kernel against on random requests"""
+        B, T = ids.shape
+        V = self.config.text_config["vocab_size"]
+        bad_vocab = bool(((ids < 0) | (ids >= V)).any())
+        bad_label = bool(((lab != -100) & ((lab < 0) | (lab >= V))).any()) if lab is not None else False
+        img_pos, bad_slot = None, False
+        if q_slot > 0:
+            s_id, e_id, t_id = special
+            is_start = ids == s_id
+            has = is_start.any(dim=1)
+            if need_tok:
+                has = has & (ids == t_id).any(dim=1)
+            p0 = is_start.int().argmax(dim=1)
+            endpos = p0 + q_slot + 1
+            ok = (endpos < T) & (ids.gather(1, endpos.clamp(max=T - 1)[:, None])[:, 0] == e_id)
+            bad_slot = bool((has & ~ok).any())
+            img_pos = torch.where(has, p0, torch.full_like(p0, -1)).to(torch.int32)
+        any_masked, hole = False, False
+        if am64 is not None:
+            vis = am64 != 0
+            any_masked = not bool(vis.all())
+            if prefix_visible:
+                vis = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=vis.device), vis], dim=1)
+            masked_after_visible = (~vis) & (vis.int().cummax(dim=1).values > 0)
+            hole = bool((vis & (masked_after_visible.int().cummax(dim=1).values > 0)).any())
+        return [bad_vocab, bad_slot, any_masked, hole, bad_label], img_pos
+
     @torch.no_grad()
     def generate(self, input_ids=None, pixel_values=None, attention_mask=None, generation_config=None, logits_processor=None,
                  stopping_criteria=None, **kwargs):

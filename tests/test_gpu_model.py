@@ -331,6 +331,76 @@ def test_edge_beam_search_matches_reference(dtype, golden_dir):
     assert greedy.shape == (2, 6)                              # num_beams = 1 is untouched by the beam path
 
 
+def test_request_check_kernel_equals_the_tensor_formulation_on_random_requests():
+    """vcla_check_request (ONE launch in front of every forward / generate) against the same five answers in tensor algebra
+    (tests/repl_stub/oracle_backed.py:_request_flags, what the CPU tests of `_check_request` run on): 300 random requests over batch sizes, row lengths either
+    side of the 64-lane chunks, well-formed / truncated / missing image slots, ids and labels at both edges of the vocabulary, masks with left padding, right
+    padding, holes and nothing visible at all, with and without the image_at_head prefix.  Flags and img_pos must be EQUAL."""
+    import sys as _sys
+    from types import SimpleNamespace
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "repl_stub"))
+    from oracle_backed import OracleBackedModel
+    import visualcla.modeling_visualcla as M
+    V, S_ID, E_ID, T_ID = 1000, 997, 998, 999
+    me = SimpleNamespace(config=SimpleNamespace(text_config={"vocab_size": V}))
+    g = torch.Generator().manual_seed(11)
+    r = lambda n: int(torch.randint(0, n, (1,), generator=g))
+    seen = [0] * 5
+    for case in range(300):
+        B, T = (1, 3, 70)[r(3)], (1, 7, 24, 63, 64, 65, 130, 257)[r(8)]
+        Q = (0, 4, 16)[r(3)]
+        ids = torch.randint(0, 990, (B, T), generator=g)
+        if Q and T > Q + 2:
+            for b in range(B):
+                kind = r(6)                                            # 0: no slot, 1 - 3: well-formed, 4: </img> missing, 5: <img> too close to the end
+                if kind == 0:
+                    continue
+                p0 = r(T - Q - 1) if kind != 5 else T - 1 - r(min(Q, T - 1) + 1)
+                ids[b, p0] = S_ID
+                if p0 + 1 < T:
+                    ids[b, p0 + 1:min(T, p0 + 1 + Q)] = T_ID
+                if kind in (1, 2, 3) and p0 + Q + 1 < T:
+                    ids[b, p0 + Q + 1] = E_ID
+                if kind == 3 and p0 + Q + 2 < T:
+                    ids[b, p0 + Q + 2 + r(T - p0 - Q - 2)] = S_ID      # a second <img> later in the row: the first one counts
+                if r(8) == 0:
+                    ids[b][ids[b] == T_ID] = 5                         # no <img_token>: forward lets the row pass as image-free
+        if r(10) == 0:
+            ids[r(B), r(T)] = (V, -1, V + 5)[r(3)]
+        am = None
+        if r(4):
+            Tm = T if r(3) else T + Q
+            am = torch.ones(B, Tm, dtype=torch.int64)
+            for b in range(B):
+                kind = r(7)                                            # 0 - 1: all ones, 2: left pad, 3: right pad, 4: hole, 5: nothing visible, 6: random
+                if kind == 2:
+                    am[b, :r(Tm + 1)] = 0
+                elif kind == 3:
+                    am[b, Tm - r(Tm + 1):] = 0
+                elif kind == 4:
+                    am[b, r(Tm)] = 0
+                elif kind == 5:
+                    am[b] = 0
+                elif kind == 6:
+                    am[b] = torch.randint(0, 2, (Tm,), generator=g)
+        lab = None
+        if r(3) == 0:
+            lab = torch.randint(0, V, (B, T), generator=g)
+            lab[:, :r(T + 1)] = -100
+            if r(4) == 0:
+                lab[r(B), r(T)] = (V, -1, -99)[r(3)]
+        need_tok, prefix = bool(r(2)), bool(r(2))
+        args = (Q, (S_ID, E_ID, T_ID), need_tok, prefix)
+        want, want_pos = OracleBackedModel._request_flags(me, ids, am, lab, *args)
+        got, got_pos = M.VisualCLAModel._request_flags(me, ids.cuda(), None if am is None else am.cuda(), None if lab is None else lab.cuda(), *args)
+        assert got == want, (case, B, T, Q, got, want)
+        if Q:
+            assert got_pos.dtype == torch.int32 and torch.equal(got_pos.cpu(), want_pos), (case, got_pos.tolist(), want_pos.tolist())
+        for i in range(5):
+            seen[i] += int(want[i])
+    assert all(n >= 5 for n in seen), seen                             # every flag was raised by some requests (and left down by most)
+
+
 def test_masks_with_interior_zeros_are_refused_by_generate_only():
     """image_at_head=True + a left-padded text mask = [1]*Q ++ [0..0, 1..1] (modeling_visualcla.py:372-377): in `generate` the transformers
     versions the reference pins derive cumsum(mask) positions, which zeros between visible tokens would make differ from the absolute

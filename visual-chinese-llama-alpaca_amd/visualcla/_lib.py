@@ -125,6 +125,7 @@ SYMBOLS = {
                                    C.POINTER(C.c_float), _vp, _i, _vp]),
     "vcla_image_preprocess_batch": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, C.POINTER(C.c_float),
                                          C.POINTER(C.c_float), _vp, _i, _vp]),
+    "vcla_check_request": (_i, [_vp, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "vcla_embed_splice": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vcla_rope_kv_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vcla_attn_decode_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _f, _i, _i, _vp]),
