@@ -1258,6 +1258,13 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             // for M >= 64, for short-N / long-K shapes (down-proj) and for N <= 4096 once M >= 32; else the skinny kernel
             const bool panel = a->W_frag || a->W_q8_frag || (a->splitk_ws && (a->M >= 64 || (a->N <= 4096 && (a->K >= 8192 || a->M >= 32))));
             kernel = panel ? 8 : 7;
+            // the resampler's 64 latent rows (K = 1024: q / kv / out / fc1): one launch of 64 x 64 ring tiles instead of K slices + a reduce launch
+            // (graph-replayed, rotating weights, M = 64: 15.8 - 18.0 -> 13.0 - 13.3 us; K = 4096 (fc2) stays: 19.2 vs 26.0).  The decode-side
+            // twins (W_frag / W_q8_frag: LLaMA rows) keep their kernels.
+            static const int ring_env = getenv("VCLA_RING") ? atoi(getenv("VCLA_RING")) : 1;
+            static const int ring_vit_env = getenv("VCLA_RING_VIT") ? atoi(getenv("VCLA_RING_VIT")) : 1;
+            if (ring_env && ring_vit_env && a->M > 16 && a->K <= 2048 && a->N >= 512 && !a->W_frag && !a->W_q8_frag && !a->W_q8 && !a->norm_gamma && !a->out_f32 &&
+                a->epilogue != VCLA_EPI_SWIGLU && a->c_group_rows <= 0 && a->A) kernel = 11;
         }
         else {
             // Ragged M (ViT: M = B*257): peel the M % 256 <= 128 tail rows into their own small launch so the 256x256 kernel
