@@ -519,6 +519,10 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const unsigned long long* mb = eg_mb(c, layer, EG_MB_QKV);
         const unsigned ep = eg_epoch(c, layer, 1);
         unsigned qd = 0, kd = 0, vd = 0;
+        // the rotation of this position does not depend on the granules: requested before the wait for them, not behind it
+        const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
+        const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * (D / 2) + i0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
         eg_st(&m->gathering, 1);
         for (unsigned it = 0;; ++it) {
             const unsigned long long xq = eg_peek(mb, h * 64 + lane), xk = eg_peek(mb, 2048 + h * 64 + lane), xv = eg_peek(mb, 4096 + h * 64 + lane);
@@ -531,9 +535,6 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         }
         eg_st(&m->gathering, 0);
         eg_stamp(c, layer, 10);
-        const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
-        const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * (D / 2) + i0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
         const float c0 = Act<bf16_t>::rnd(cs.x), c1 = Act<bf16_t>::rnd(cs.y), s0 = Act<bf16_t>::rnd(sn.x), s1 = Act<bf16_t>::rnd(sn.y);
         const bool hi_half = lane >= 32;
         const float q0 = eg_lo(qd), q1 = eg_hi(qd), k0 = eg_lo(kd), k1 = eg_hi(kd);
