@@ -285,6 +285,25 @@ def main():
                 t = timeit(lambda: _lib.gemm(a, w, N, bias=bias, epilogue=epi, out=out, force_kernel=fk, splitk_ws=skws))
                 tf = 2.0 * Mv * N * K / t / 1e12
                 print(f"vit   {tag:4s} {nm} M={Mv} N={N:5d} K={K:5d}  {t*1e6:8.1f} us  {tf:7.1f} TF/s ({tf/25:.1f}% of peak)")
+    if "vit1" in which:
+        print("== ONE image through the ViT / the resampler (257 / 64 rows; bias, residual on out / fc2): the K-slice dispatch of rounds 3 - 5 (auto + workspace: 128 x 128 tiles,")
+        print("   K slices, reduce launch) vs the ring tiles over the full K (k14 = 64 x 64, k13 = 128 x 96), graph-replayed, rotating 4 weight matrices")
+        skws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        for M in (257, 64):
+            for tag, N, K, res in (("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)):
+                a, ws, bias = rnd(M, K), [packw(N, K) for _ in range(4)], torch.randn(N, device=DEV)
+                r = rnd(M, N) if res else None
+                out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+                line = f"vit1 M={M:3d} {tag:4s} N={N:5d} K={K:5d}: "
+                for fk, nm, env in ((0, "K slices + reduce", "0"), (14, "ring 64x64", "1"), (13, "ring 128x96", "1")):
+                    os.environ["VCLA_RING_VIT"] = env
+                    i = [0]
+                    def run():
+                        i[0] = (i[0] + 1) % 4
+                        _lib.gemm(a, ws[i[0]], N, bias=bias, residual=r, out=out, force_kernel=fk, splitk_ws=(skws if fk == 0 else None))
+                    line += f"{nm} {timeit_graph(run, reps=50) * 1e6:6.1f} us | "
+                os.environ.pop("VCLA_RING_VIT", None)
+                print(line, flush=True)
     if "vittail" in which:
         print("== the 64-row ragged-M tail of the ViT GEMMs at B=64: split-K panel + reduce (8) vs skinny, one launch (7)")
         skws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)

@@ -44,6 +44,12 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES; do pmc $c tool
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE; do pmc $c tools/pmc_vit_attn.py attn_vit_dma_kernel ${tag}_pmc_vit_attn.txt; done
 echo "== engine A/B + timeline (full 7B)"; timeout 900 python tools/engine_probe.py --layers 32 --vocab 49958 --steps 3 --time 64 --timeline 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${tag}_engine_vs_launches.txt
 echo "== bench with the engine off (VCLA_ENGINE=0: the round-5 launch path, same box)"; VCLA_ENGINE=0 timeout 600 python bench.py --steps 3 --warmup 1 --steps-b64 0 --steps-c4 0 --steps-strong 0 --steps-strong-c4 0 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench_engine_off.json; cut -c1-300 gpurun_out/${tag}_bench_engine_off.json
+echo "== B = 1 time to first token (one image, T = 128): wall clock, then the kernels of one request (rocprofv3 --kernel-trace of the same script)"
+(timeout 300 python tools/prof_ttft.py 20 2>&1 | grep "^B="; echo "-- VCLA_RING_VIT=0 (round-5 dispatch of the one-image ViT / resampler GEMMs)"; VCLA_RING_VIT=0 timeout 300 python tools/prof_ttft.py 20 2>&1 | grep "^B=") | tee gpurun_out/${tag}_ttft_b1.txt
+rm -rf gpurun_out/prof_ttft
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_ttft -o t -- python $R/tools/prof_ttft.py 10 2>&1 | grep "^B=")
+f=$(find gpurun_out/prof_ttft -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/prof_by_grid.py $f 40 | grep -v "at::native" | tee -a gpurun_out/${tag}_ttft_b1.txt
+rm -rf gpurun_out/prof_ttft
 echo "== microbench"
-(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py dec256 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
+(python tools/bench_kernels.py gemv1 2>&1 | grep "^gemv1"; VCLA_BENCH_MS=64 python tools/bench_kernels.py dstream 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py dec256 2>&1 | grep -E "^M=|^=="; python tools/bench_kernels.py vit vittail vitattn attndec vit1 2>&1 | grep -E "^vit|^attn"; echo "-- sustained (400 launches per figure)"; VCLA_BENCH_REPS=400 python tools/bench_kernels.py vit 2>&1 | grep "^vit") | tee gpurun_out/${tag}_kernel_microbench.txt
 echo "== done"

@@ -1086,6 +1086,8 @@ extern "C" int vcla_llama_decode_status(vcla_ctx* ctx, int B, const void* ws, si
     carve_llama(ctx, B, 1, (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &w);
     unsigned st[2] = {0, 0};
     VCLA_CHECK_HIP(hipMemcpy(st, (const char*)w.eng + EG_WS_STATE_OFF, sizeof st, hipMemcpyDeviceToHost));
-    if (st[1]) return vcla_fail(VCLA_ERR_HIP, "decode engine: a wait timed out (site 0x%x on CU %u after %u launches); its output is invalid", st[1] & 0xffffu, st[1] >> 16, st[0]);
+    if (st[1]) return vcla_fail(VCLA_ERR_HIP, "decode engine: a wait timed out (site 0x%x on CU %u after %u launches); its output is invalid.  The persistent launch needs all %d CUs to itself "
+                                                   "(one workgroup each, co-resident): on a shared or partitioned GPU set VCLA_ENGINE=0 to decode on the per-operator launches",
+                               st[1] & 0xffffu, st[1] >> 16, st[0], EG_NCU);
     return VCLA_OK;
 }

@@ -1262,7 +1262,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             // (graph-replayed, rotating weights, M = 64: 15.8 - 18.0 -> 13.0 - 13.3 us; K = 4096 (fc2) stays: 19.2 vs 26.0).  The decode-side
             // twins (W_frag / W_q8_frag: LLaMA rows) keep their kernels.
             static const int ring_env = getenv("VCLA_RING") ? atoi(getenv("VCLA_RING")) : 1;
-            static const int ring_vit_env = getenv("VCLA_RING_VIT") ? atoi(getenv("VCLA_RING_VIT")) : 1;
+            const char* rv_ = getenv("VCLA_RING_VIT"); const int ring_vit_env = rv_ ? atoi(rv_) : 1;      // read per call: tools/bench_kernels.py vit1 flips it
             if (ring_env && ring_vit_env && a->M > 16 && a->K <= 2048 && a->N >= 512 && !a->W_frag && !a->W_q8_frag && !a->W_q8 && !a->norm_gamma && !a->out_f32 &&
                 a->epilogue != VCLA_EPI_SWIGLU && a->c_group_rows <= 0 && a->A) kernel = 11;
         }
@@ -1307,7 +1307,7 @@ static int gemm_impl(const vcla_gemm_args* a, int dtype, void* stream) {
             // ONE image through the ViT (257 rows, K = 1024: qkv / out / fc1): 72 - 96 tiles of 128 x 128 needed K slices + a reduce launch to fill the chip; 64 x 64
             // (128 x 96) ring tiles over the full K fill it in one launch with the bias / GELU / residual in the tile's epilogue.  Graph-replayed, rotating weights,
             // M = 257: qkv 25.4 -> 14.0 us, out 17.8 -> 13.5, fc1 28.0 -> 18.0; fc2 (K = 4096) stays on the K slices (24.2 vs 26.2).  VCLA_RING_VIT=0: off.
-            static const int ring_vit_env = getenv("VCLA_RING_VIT") ? atoi(getenv("VCLA_RING_VIT")) : 1;
+            const char* rv_ = getenv("VCLA_RING_VIT"); const int ring_vit_env = rv_ ? atoi(rv_) : 1;      // read per call: tools/bench_kernels.py vit1 flips it
             if (ring_env && ring_vit_env && a->M <= 320 && a->K <= 2048 && !a->out_f32 && a->epilogue != VCLA_EPI_SWIGLU && a->c_group_rows <= 0 && a->A && !a->W_q8) kernel = 11;
         }
     }
