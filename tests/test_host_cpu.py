@@ -775,8 +775,10 @@ def test_engine_stream_is_every_cu_s_weights_in_consumption_order():
             W.add_engine_stream(packed, D, H, inter, V, L)
         finally:
             W.engine_geometry = orig
-        st = packed["llama.engine.w"].float()
-        assert st.shape == (256, g["slots_total"], 2 * D) and torch.equal(packed["llama.engine.g"][:, 0], torch.tensor([1.0, 2.0, 3.0]))
+        # in memory: [slot][CU][16 KiB] -- slot g of CU c at (g * 256 + c) * 16 KiB (the loaders of all CUs sweep one moving window); read here per CU
+        assert packed["llama.engine.w"].shape == (g["slots_total"], 256, 2 * D) and packed["llama.engine.w"].is_contiguous()
+        st = packed["llama.engine.w"].float().permute(1, 0, 2)
+        assert torch.equal(packed["llama.engine.g"][:, 0], torch.tensor([1.0, 2.0, 3.0]))
         upc, gpc = g["upc"], g["gpc"]
         cu = torch.arange(256)
         # qkv: slot j of CU c = rows part*D + (c // 8)*128 + (c % 8)*16 + 2 (j % 8), + 1 with part = j // 8

@@ -29,6 +29,7 @@ struct vcla_engine_geom {
     int s_dn;           // down_proj slots per CU = ceil(2 * ceil(upc / 2) * 256 / 512): K in granule order, 512 k per slot
     int s_lm;           // lm_head slots per CU (2 rows each)
     int slots_layer, slots_total;
+    size_t cu_stride, slot_stride;      // bytes between the runs of consecutive CUs / between consecutive slots of one CU
 };
 // false when the model cannot run on the engine (geometry); fills g otherwise
 bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_layers, vcla_engine_geom* g);

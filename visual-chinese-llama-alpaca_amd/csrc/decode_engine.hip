@@ -757,7 +757,8 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
 
 __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ring_u, EgMisc* m, unsigned* state, int cu, int lane) {
     const int total = a.g.slots_total;
-    const unsigned char* src = a.stream + (size_t)cu * (size_t)total * EG_SLOT + lane * 16;
+    const unsigned char* src = a.stream + (size_t)cu * a.g.cu_stride + lane * 16;
+    const size_t slot_stride = a.g.slot_stride;
     unsigned pub = 0;
     unsigned long long stall = 0, n_stall = 0;
     const unsigned long long t_begin = a.timeline ? wall_clock64() : 0ull;
@@ -777,7 +778,7 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
             }
         }
         const unsigned dst = ring_u + p * EG_SLOT;
-        const unsigned char* s = src + (size_t)g * EG_SLOT;
+        const unsigned char* s = src + (size_t)g * slot_stride;
 #pragma unroll
         for (int i = 0; i < 16; ++i) eg_dma16_nt(s + i * 1024, dst + i * 1024);
         unsigned landed;
@@ -825,6 +826,7 @@ bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_lay
     g->s_lm = (vocab + 2 * EG_NCU - 1) / (2 * EG_NCU);
     g->slots_layer = EG_S_QKV + EG_S_O + upc + gpc;
     g->slots_total = n_layers * g->slots_layer + g->s_lm;
+    g->cu_stride = EG_SLOT; g->slot_stride = (size_t)EG_NCU * EG_SLOT;                          // [slot][CU][16 KiB]
     return true;
 }
 

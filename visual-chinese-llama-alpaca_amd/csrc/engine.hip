@@ -373,6 +373,11 @@ extern "C" int vcla_ctx_finalize(vcla_ctx* ctx) {
         int rc = get_tensor_opt(ctx, "llama.engine.w", (size_t)EG_NCU * ctx->eng_geom.slots_total * EG_SLOT, &ew);
         if (!rc) rc = get_tensor_opt(ctx, "llama.engine.g", (size_t)(2 * c.t_layers + 1) * EG_D * 4, &eg);
         if (rc) return rc;
+        if (!rc && !ew) {      // A/B only: "llama.engine.w.cu" = the first form of the round, [CU][slot][16 KiB] (every CU's run contiguous)
+            rc = get_tensor_opt(ctx, "llama.engine.w.cu", (size_t)EG_NCU * ctx->eng_geom.slots_total * EG_SLOT, &ew);
+            if (rc) return rc;
+            if (ew) { ctx->eng_geom.cu_stride = (size_t)ctx->eng_geom.slots_total * EG_SLOT; ctx->eng_geom.slot_stride = EG_SLOT; }
+        }
         if (ew && eg) { ctx->eng_w = ew; ctx->eng_g = (const float*)eg; }
     }
     ctx->finalized = true;

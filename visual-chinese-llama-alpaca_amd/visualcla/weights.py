@@ -18,6 +18,7 @@ and the flat `vision_model.*` of transformers 5.x.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict
 
 import torch
@@ -168,12 +169,15 @@ def engine_down_kmap(inter: int) -> torch.Tensor:
 
 
 def add_engine_stream(packed: Dict[str, torch.Tensor], hidden: int, heads: int, inter: int, vocab: int, n_layers: int) -> Dict[str, torch.Tensor]:
-    """`llama.engine.w` [256 CUs][slots_total][8192] bf16 + `llama.engine.g` [2 L + 1][4096] fp32: a THIRD copy of the LLaMA matrices (13.4 GB at
-    7B; HBM is 288 GB) in which every CU's share of every operator is one contiguous run of 16-KiB slots in the order the persistent decode step
-    consumes them -- its loader wave streams the region front to back without knowing what an operator is.  Per layer and CU c (head h = c // 8,
-    s = c % 8): 24 slots of wqkv (2 rows each: q, k, v rows h*128 + s*16 + 2j), 8 of wo (K-major: rows 16c .. 16c + 15 x 512 k), upc of wgu (gate row + up
-    row of unit upc*c + j), gpc of wd (K-major: 16 rows x 512 k', k' in granule order, engine_down_kmap); after the layers s_lm slots of lm_head (rows
-    2 s_lm c + 2j).  Nothing is added when the geometry does not fit (the launch path serves the model)."""
+    """`llama.engine.w` [slots_total][256 CUs][8192] bf16 + `llama.engine.g` [2 L + 1][4096] fp32: a THIRD copy of the LLaMA matrices (13.4 GB at
+    7B; HBM is 288 GB) cut into 16-KiB slots in the order the persistent decode step consumes them -- CU c's loader wave reads slot g at
+    (g * 256 + c) * 16 KiB, front to back, without knowing what an operator is.  SLOT-major: the 256 loaders advance together, so at any moment the chip
+    reads ONE moving window of a few MiB, the access pattern of a plain copy.  (The first form of the round kept every CU's run contiguous -- 256 concurrent
+    sequential streams 52 MB apart: 5 % slower on average and anywhere between 2.24 and 2.40 ms per step depending on WHERE the allocation landed in HBM,
+    profiles/r06_engine_placement.txt; slot-major: 2.156 - 2.170 wherever it lands.)  Per layer and CU c (head h = c // 8, s = c % 8): 24 slots of wqkv
+    (2 rows each: q, k, v rows h*128 + s*16 + 2j), 8 of wo (K-major: rows 16c .. 16c + 15 x 512 k), upc of wgu (gate row + up row of unit upc*c + j),
+    gpc of wd (K-major: 16 rows x 512 k', k' in granule order, engine_down_kmap); after the layers s_lm slots of lm_head (rows 2 s_lm c + 2j).  Nothing is
+    added when the geometry does not fit (the launch path serves the model)."""
     g = engine_geometry(hidden, heads, inter, vocab, n_layers)
     if g is None or "llama.lm_head" not in packed:
         return packed
@@ -202,7 +206,10 @@ def add_engine_stream(packed: Dict[str, torch.Tensor], hidden: int, heads: int, 
     lmp[vocab:] = 0
     stream[:, n_layers * SL:] = lmp.view(N, s_lm, 2 * D)
     gam = [packed[f"llama.l{l}.ln{i}.g"] for l in range(n_layers) for i in (1, 2)] + [packed["llama.norm.g"]]
-    packed["llama.engine.w"] = stream
+    if os.environ.get("VCLA_ENGINE_LAYOUT", "slot") == "cu":        # A/B only (tools/debug/engine_variance.py): the first form of round 6, every CU's run contiguous
+        packed["llama.engine.w.cu"] = stream
+    else:
+        packed["llama.engine.w"] = stream.permute(1, 0, 2).contiguous()
     packed["llama.engine.g"] = torch.stack(gam, 0).to(torch.float32).contiguous()
     return packed
 
