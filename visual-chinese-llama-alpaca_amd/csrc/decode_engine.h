@@ -36,7 +36,7 @@ bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_lay
 
 struct vcla_engine_args {
     vcla_engine_geom g;
-    const unsigned char* stream;   // "llama.engine.w": [256 CUs][slots_total][16 KiB], every CU's weights in consumption order
+    const unsigned char* stream;   // "llama.engine.w": [slots_total][256 CUs][16 KiB] (g.slot_stride / g.cu_stride), every CU's weights in consumption order
     const float* gamma;            // "llama.engine.g": [2 L + 1][4096] fp32: ln1 / ln2 of every layer, then the final norm
     const bf16_t* x_in;            // [4096] embedding of the current token
     bf16_t* kv;                    // K/V cache [L][2][1][H][ctx_max][d] bf16
