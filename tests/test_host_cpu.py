@@ -809,3 +809,11 @@ def test_engine_stream_is_every_cu_s_weights_in_consumption_order():
     assert W.engine_geometry(4096, 32, 11008, 49958, 32) == dict(upc=43, gpc=22, s_lm=98, slots_layer=97, slots_total=32 * 97 + 98)
     assert W.engine_geometry(5120, 40, 13824, 49958, 40) is None and W.engine_geometry(4096, 32, 11008 + 64, 49958, 32) is None
     assert W.engine_geometry(4096, 32, 1024, 49958, 2) is None and W.engine_geometry(4096, 32, 11008, 1000, 2) is None
+
+
+def test_graft_entry_build_is_what_the_driver_runs():
+    """`__graft_entry__.build()` -- the driver's "does it build" check -- must pass on this tree: make (incremental), import, and the library's ABI version
+    against the header's (round 6 shipped most of its commits with a stale `== 4` there: nothing in the suite ran it)"""
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "build ok" in r.stdout
