@@ -170,3 +170,32 @@ def test_a_workgroup_that_never_publishes_is_a_status_code_not_a_hang(small7b):
     finally:
         os.environ.pop("VCLA_ENGINE_FAULT", None)
     assert torch.equal(m.generate(**kw), good)
+
+
+def test_engine_soak_many_calls_of_changing_shape(small7b):
+    """60 generate() calls in one process with prompt lengths, new-token counts, masks and graph / eager loops changing from call to call: every call must end
+    with a clean decode status (no wait ran out: `generate()` checks it), return finite in-vocabulary tokens of the right shape, and repeat exactly when the same
+    call is made again later (launch sequence numbers, mailbox parities and cached step graphs carry nothing from one call into the next)."""
+    m = small7b
+    os.environ["VCLA_ENGINE"] = "1"
+    V = m.config.text_config["vocab_size"]
+    g = torch.Generator().manual_seed(23)
+    r = lambda n: int(torch.randint(0, n, (1,), generator=g))
+    first = {}
+    calls = []
+    for i in range(40):
+        T, n_new, graph, masked = 1 + r(300), 1 + r(40), bool(r(2)), r(4) == 0
+        calls.append((T, n_new, graph, masked, 100 + i))
+    calls += [calls[j] for j in (3, 17, 0, 29, 8, 21, 35, 12, 5, 38, 26, 1, 33, 14, 9, 30, 19, 7, 24, 11)]      # repeats, in another order
+    for k, (T, n_new, graph, masked, seed) in enumerate(calls):
+        ids = torch.randint(3, V - 8, (1, T), generator=torch.Generator().manual_seed(seed)).to(m.device)
+        am = None
+        if masked and T > 4:
+            am = torch.ones(1, T, dtype=torch.int64, device=m.device)
+            am[0, :1 + (seed % (T // 2))] = 0                                   # left padding
+        toks = m.generate(input_ids=ids, attention_mask=am, max_new_tokens=n_new, do_sample=False, eos_token_id=None, use_graph=graph)
+        assert toks.shape == (1, n_new) and int(toks.min()) >= 0 and int(toks.max()) < V, (k, T, n_new, toks.shape)
+        key = (T, n_new, masked, seed)                                          # graph or eager: the same tokens
+        if key in first:
+            assert torch.equal(first[key], toks.cpu()), (k, key)
+        first[key] = toks.cpu()
