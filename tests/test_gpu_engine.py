@@ -63,7 +63,8 @@ def _steps(m, mode, T, n_steps, masked, forced=None):
     return toks, lgs, cache.kv[..., :T + n_steps, :].float().clone()
 
 
-@pytest.mark.parametrize("T,masked", [(160, False), (37, False), (200, True), (1, False), (1011, False), (700, True)])
+# 510 / 509: the four steps cross args.split_min = 512 inside one loop (one CU per head -> the head's 8 CUs share the cache walk); 1011 / 700 / 1900: split throughout
+@pytest.mark.parametrize("T,masked", [(160, False), (37, False), (200, True), (1, False), (1011, False), (700, True), (510, False), (509, True), (1900, False)])
 def test_engine_steps_match_the_launch_path(small7b, T, masked):
     """logits of every decode step (teacher-forced on the launch path's tokens) and the K / V rows both forms append: within bf16 rounding of each other.
     Bounds: the two forms round the RMSNorm output differently (the engine to bf16 once, the launches keep fp32) and sum in different orders; measured at
@@ -199,3 +200,22 @@ def test_engine_soak_many_calls_of_changing_shape(small7b):
         if key in first:
             assert torch.equal(first[key], toks.cpu()), (k, key)
         first[key] = toks.cpu()
+
+
+def test_split_attention_equals_the_one_cu_walk(small7b):
+    """args.split_min (VCLA_ENGINE_SPLIT): above it the 8 CUs of a head's group share the walk over its cached keys and the owner merges their (o, m, l);
+    below it one CU walks alone.  Same keys, same arithmetic per key, another summation order: the logits of the two forms must agree to fp32 rounding of the
+    softmax sums (far inside the bf16 bound of the other tests) at contexts either side of the default threshold."""
+    m = small7b
+    for T in (300, 700, 1500):
+        got = {}
+        for mode in ("0", "128"):                       # never split | split from 128 cached keys on
+            os.environ["VCLA_ENGINE_SPLIT"] = mode
+            try:
+                got[mode] = _steps(m, "1", T, 3, masked=(T == 700))
+            finally:
+                os.environ.pop("VCLA_ENGINE_SPLIT", None)
+        for s in range(3):
+            d = (got["0"][1][s] - got["128"][1][s]).abs()
+            assert d.max().item() < 0.06 and d.mean().item() < 0.01, (T, s, d.max().item(), d.mean().item())
+        assert (got["0"][2] - got["128"][2]).abs().max().item() < 0.05          # the appended K / V rows

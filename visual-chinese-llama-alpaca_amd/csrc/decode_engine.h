@@ -11,14 +11,16 @@
 #define EG_S_QKV 24            // slots per CU and layer: 48 rows of wqkv (16 q + 16 k + 16 v rows of ONE head), 2 rows per slot
 #define EG_S_O 8               // 16 rows of wo, K-major: slot j = the 16 rows x k in [512 j, 512 j + 512)
 #define EG_NRING 9             // LDS ring slots
-// mailboxes (8-byte {tag, two bf16} granules), per layer parity: X | QKV | AO | X1 | ACT
+// mailboxes (8-byte {tag, two bf16} granules), per layer parity: X | QKV | AO | X1 | ACT | PART
 #define EG_MB_X 0
 #define EG_MB_QKV 2048
 #define EG_MB_AO (2048 + 6144)
 #define EG_MB_X1 (2048 + 6144 + 2048)
 #define EG_MB_ACT (2048 + 6144 + 2048 + 2048)
 #define EG_MB_MAX_ACT 5632     // intermediate <= 11264 (44 granule slots per CU)
-#define EG_MB_PER_PARITY (EG_MB_ACT + EG_MB_MAX_ACT)
+#define EG_MB_PART (EG_MB_ACT + EG_MB_MAX_ACT)      // split attention: [32 heads][8 CUs of the group][136]: unnormalised o[128], m, l as fp32 granules
+#define EG_PART_GRAN 136
+#define EG_MB_PER_PARITY (EG_MB_PART + EG_H * 8 * EG_PART_GRAN)
 #define EG_WS_STATE_OFF ((size_t)2 * EG_MB_PER_PARITY * 8)           // state words behind the mailboxes: [0] launch sequence, [1] failure code
 #define EG_WS_BYTES (EG_WS_STATE_OFF + 256)
 #define EG_TL_STRIDE 2048      // debug stamps per CU: 16 per layer (leader), then loader totals at [2040..]
@@ -56,6 +58,7 @@ struct vcla_engine_args {
     int32_t* tail_pos;
     int tail_step_base;
     int fault;                     // test hook (VCLA_ENGINE_FAULT=1): the consumers of CU 7 leave at once -- every wait on their outputs must run out, not hang
+    int split_min;                 // contexts of at least this many cached keys split a head's attention over the 8 CUs of its group (0: never)
     int thin;                      // loader keeps ONE fill in flight while its CU sweeps a mailbox (MI355X_MICROARCH.md gather-pass) / 0: never thins
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };

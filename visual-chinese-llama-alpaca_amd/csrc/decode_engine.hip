@@ -482,9 +482,14 @@ __device__ __forceinline__ bool eg_run_kmajor(EgCtx& c, int g0, int nslots, int 
 // ---- attention of one head on this CU's three consumers (RoPE + cache append + single-pass online softmax over the cache; the arithmetic of
 // attn_decode_flash_kernel<128, NW, MASK>, attention_decode.hip, with NW = 3).  U keys per lane group and batch, two batches in flight.
 // (8 keys per batch = 192 keys requested before q exists; the MASK instantiation is 8 registers short for that with o_proj slots held across this code: 6)
-template <bool MASK, bool LEADER>
+// SPLIT (long contexts, args.split_min): the head's cached keys are dealt over all 8 CUs of its group (CU 8 h + s takes the key streams 12 s .. 12 s + 11 of
+// 96); the 7 helpers (OWNER = false) publish their unnormalised (o[128], m, l) as fp32 granules and the owner merges them with its own share and the new
+// token.  One more hand-off on the layer's critical path (~2 - 3 us), 7/8 of the cache walk off it (~1 us per 100 keys on ONE CU).
+template <bool MASK, bool LEADER, bool OWNER, bool split, bool SPLITK = split>
 __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
-    constexpr int D = EG_HD, LPK = 16, KPW = 4, KPB = 12, U = MASK ? 6 : 8;
+    constexpr int D = EG_HD, LPK = 16, KPW = 4, U = (MASK || SPLITK) ? 6 : 8;       // (8 keys per batch only where the registers allow: the short-context kernel without a mask)
+    constexpr int KPB = split ? 96 : 12;                             // key streams of the head: 12 per CU
+    static_assert(OWNER || split, "a helper exists only when the walk is split");
     const vcla_engine_args& a = *c.a;
     EgMisc* m = c.m;
     const int h = c.cu >> 3, pos = c.pos, lane = c.lane;
@@ -492,7 +497,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     bf16_t* kbase = a.kv + (size_t)(2 * layer) * per + (size_t)h * a.ctx_max * D;
     bf16_t* vbase = kbase + per;
     const int32_t* km = a.key_mask;
-    const int cch = lane % LPK, grp = c.w * KPW + lane / LPK;
+    const int cch = lane % LPK, lgrp = c.w * KPW + lane / LPK, grp = (split ? (c.cu & 7) * 12 : 0) + lgrp;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(kbase, 0, a.ctx_max * D * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vbase, 0, a.ctx_max * D * 2, 0x00020000);
     u32x4_t kA[U], vA[U], kB[U], vB[U];
@@ -525,7 +530,8 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
         eg_st(&m->gathering, 1);
         for (unsigned it = 0;; ++it) {
-            const unsigned long long xq = eg_peek(mb, h * 64 + lane), xk = eg_peek(mb, 2048 + h * 64 + lane), xv = eg_peek(mb, 4096 + h * 64 + lane);
+            const unsigned long long xq = eg_peek(mb, h * 64 + lane);
+            const unsigned long long xk = OWNER ? eg_peek(mb, 2048 + h * 64 + lane) : xq, xv = OWNER ? eg_peek(mb, 4096 + h * 64 + lane) : xq;      // (a helper needs q only)
             qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
             const bool good = (unsigned)(xq >> 32) == ep && (unsigned)(xk >> 32) == ep && (unsigned)(xv >> 32) == ep;
             if (__all(good)) break;
@@ -545,10 +551,12 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const float rk0 = Act<bf16_t>::rnd(hi_half ? k0 * c0 + pk0 * s0 : k0 * c0 - pk0 * s0);
         const float rk1 = Act<bf16_t>::rnd(hi_half ? k1 * c1 + pk1 * s1 : k1 * c1 - pk1 * s1);
         m->qpk[lane] = pack_bf2(rq0, rq1);
-        m->knew[2 * lane] = rk0; m->knew[2 * lane + 1] = rk1;
-        m->vnew[2 * lane] = eg_lo(vd); m->vnew[2 * lane + 1] = eg_hi(vd);
-        reinterpret_cast<unsigned*>(kbase + (size_t)pos * D)[lane] = pack_bf2(rk0, rk1);
-        reinterpret_cast<unsigned*>(vbase + (size_t)pos * D)[lane] = vd;
+        if constexpr (OWNER) {
+            m->knew[2 * lane] = rk0; m->knew[2 * lane + 1] = rk1;
+            m->vnew[2 * lane] = eg_lo(vd); m->vnew[2 * lane + 1] = eg_hi(vd);
+            reinterpret_cast<unsigned*>(kbase + (size_t)pos * D)[lane] = pack_bf2(rk0, rk1);
+            reinterpret_cast<unsigned*>(vbase + (size_t)pos * D)[lane] = vd;
+        }
         eg_release();
         eg_st(&m->attn_ready, seq);
         eg_stamp(c, layer, 11);
@@ -595,7 +603,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     }
 #undef EG_FD_LOAD
 #undef EG_FD_COMPUTE
-    {   // the new token (key / value in LDS): every group computes it, group 0 of the workgroup folds it in
+    if constexpr (OWNER) {   // the new token (key / value in LDS): every group computes it, group 0 of the owner's workgroup folds it in
         float d_ = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -604,7 +612,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
             d_ = __builtin_fmaf(eg_hi(qq), m->knew[cch * 8 + e + 1], d_);
         }
         d_ = eg_row_sum(d_);
-        const float s_ = (grp == 0 && (!MASK || km[pos] != 0)) ? d_ * sl2 : -INFINITY;
+        const float s_ = (lgrp == 0 && (!MASK || km[pos] != 0)) ? d_ * sl2 : -INFINITY;
         const float mn_ = fmaxf(m_run, s_);
         const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
         const float al_ = __builtin_amdgcn_exp2f(m_run - mu_), p_ = __builtin_amdgcn_exp2f(s_ - mu_);
@@ -636,10 +644,11 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         eg_stamp(c, layer, 12);
         if (!eg_wait_ge(&m->attn_done[1], seq, m, c.state, 0x33) || !eg_wait_ge(&m->attn_done[2], seq, m, c.state, 0x34)) return false;
         eg_acquire();
-        if (lane < 16) {
-            float mf = fmaxf(fmaxf(m->part[0][D], m->part[1][D]), m->part[2][D]);
+        float mf = fmaxf(fmaxf(m->part[0][D], m->part[1][D]), m->part[2][D]);      // (every lane: the 3 waves of this CU)
+        float lf = 0.f, o8[8];
+        {
             const float mu_ = mf == -INFINITY ? 0.f : mf;
-            float lf = 0.f, o8[8];
+            const int l16 = lane & 15;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = 0.f;
 #pragma unroll
@@ -648,13 +657,86 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
                 const float a_ = __builtin_amdgcn_exp2f(pw[D] - mu_);
                 lf += pw[D + 1] * a_;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] += pw[lane * 8 + e] * a_;
+                for (int e = 0; e < 8; ++e) o8[e] += pw[l16 * 8 + e] * a_;
             }
-            const float inv = lf > 0.f ? 1.0f / lf : 0.f;
-            unsigned long long* mbo = eg_mb(c, layer, EG_MB_AO);
-            const unsigned epo = eg_epoch(c, layer, 2);
+        }
+        if constexpr (split) {
+            unsigned long long* mbp = eg_mb(c, layer, EG_MB_PART) + (size_t)h * 8 * EG_PART_GRAN;
+            const unsigned epp = eg_epoch(c, layer, 6);
+            if constexpr (!OWNER) {
+                // a helper: its unnormalised share goes to the owner as fp32 granules
+                unsigned long long* mine = mbp + (size_t)(c.cu & 7) * EG_PART_GRAN;
+                if (lane < 16) {
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) eg_publish(mbo, h * 64 + lane * 4 + e / 2, epo, pack_bf2(o8[e] * inv, o8[e + 1] * inv));
+                    for (int e = 0; e < 8; ++e) eg_publish(mine, lane * 8 + e, epp, __float_as_uint(o8[e]));
+                    if (lane == 0) { eg_publish(mine, D, epp, __float_as_uint(mf)); eg_publish(mine, D + 1, epp, __float_as_uint(lf)); }
+                }
+                return true;
+            } else {
+                // the owner: lane group g merges the shares of CUs g and g + 4 of the head's group (its own: the registers above), then the groups meet
+                const int own = c.cu & 7, g = lane >> 4, l16 = lane & 15;
+                // (one share at a time: both in registers at once spill next to the o_proj slots held across this code)
+                float rm = -INFINITY, rl = 0.f, ro[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ro[e] = 0.f;
+                eg_st(&m->gathering, 1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int p = g + 4 * k;
+                    const unsigned long long* src = mbp + (size_t)p * EG_PART_GRAN;
+                    float pm = mf, pl = lf, po[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) po[e] = o8[e];
+                    for (unsigned it = 0;; ++it) {
+                        bool good = true;
+                        if (p != own) {
+                            const unsigned long long xm = eg_peek(src, D), xl = eg_peek(src, D + 1);
+                            good = (unsigned)(xm >> 32) == epp && (unsigned)(xl >> 32) == epp;
+                            pm = __uint_as_float((unsigned)xm); pl = __uint_as_float((unsigned)xl);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const unsigned long long xo = eg_peek(src, l16 * 8 + e);
+                                good = good && (unsigned)(xo >> 32) == epp;
+                                po[e] = __uint_as_float((unsigned)xo);
+                            }
+                        }
+                        if (__all(good)) break;
+                        if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
+                        if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x35); eg_st(&m->gathering, 0); return false; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    const float mn_ = fmaxf(rm, pm);
+                    const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+                    const float a0 = __builtin_amdgcn_exp2f(rm - mu_), a1 = __builtin_amdgcn_exp2f(pm - mu_);
+                    rm = mn_; rl = rl * a0 + pl * a1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ro[e] = ro[e] * a0 + po[e] * a1;
+                }
+                eg_st(&m->gathering, 0);
+                mf = rm; lf = rl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = ro[e];
+#pragma unroll
+                for (int off = 16; off < 64; off <<= 1) {
+                    const float m2 = __shfl_xor(mf, off, 64), l2 = __shfl_xor(lf, off, 64);
+                    const float mn_ = fmaxf(mf, m2);
+                    const float mu_ = mn_ == -INFINITY ? 0.f : mn_;
+                    const float a1 = __builtin_amdgcn_exp2f(mf - mu_), a2 = __builtin_amdgcn_exp2f(m2 - mu_);
+                    lf = lf * a1 + l2 * a2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = o8[e] * a1 + __shfl_xor(o8[e], off, 64) * a2;
+                    mf = mn_;
+                }
+            }
+        }
+        if constexpr (OWNER) {
+            if (lane < 16) {
+                const float inv = lf > 0.f ? 1.0f / lf : 0.f;
+                unsigned long long* mbo = eg_mb(c, layer, EG_MB_AO);
+                const unsigned epo = eg_epoch(c, layer, 2);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) eg_publish(mbo, h * 64 + lane * 4 + e / 2, epo, pack_bf2(o8[e] * inv, o8[e + 1] * inv));
+            }
         }
     }
     return true;
@@ -662,12 +744,17 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
 
 // One consumer wave over the whole step.  LEADER = consumer 0: sweeps the mailboxes, stages every operator's input vector, finishes down_proj,
 // owns no slot among the first 2 * NP of an operator; consumers 1 / 2 pull those into registers while the leader sweeps.
-template <bool MASK, bool LEADER>
+// SPLITK: this instantiation contains the split attention (kernels launched for caches that can outgrow args.split_min; the short-context kernel is
+// the code of the round's first form, bit for bit: carrying the split variants costs it 0.5 - 1 % -- SGPR spills, a third more code)
+template <bool MASK, bool LEADER, bool SPLITK>
 __device__ __forceinline__ void eg_consumer(EgCtx& c) {
     const vcla_engine_args& a = *c.a;
     const vcla_engine_geom& G = a.g;
     EgMisc* m = c.m;
     const bool attn_cu = (c.cu & 7) == ((c.cu >> 3) & 7);
+    // long context: the 8 CUs of a head's group share its cache walk (eg_attention).  (`split_min > 0` is implied by SPLITK; written out because hipcc's
+    // register allocation of the WHOLE kernel hinges on it: without the redundant test the split-capable kernels spill 16 - 25 registers to scratch)
+    const bool split = SPLITK && a.split_min > 0 && c.pos >= a.split_min;
     // the leader may overwrite xin only when the other consumers have finished the operator that reads it
     auto others_done = [&](unsigned seq) -> bool {
         return eg_wait_ge(&m->cons_done[1], seq, m, c.state, 0x41) && eg_wait_ge(&m->cons_done[2], seq, m, c.state, 0x42);
@@ -698,7 +785,14 @@ __device__ __forceinline__ void eg_consumer(EgCtx& c) {
             // o_proj's first slots go into registers BEFORE the attention: the ring then takes the first gate/up slots while the attention runs
             u32x4_t pre_o[NPO][16];
             if (!eg_preload<EG_OP_O>(c, g0 + EG_S_QKV, pre_o)) return;
-            if (attn_cu && !eg_attention<MASK, LEADER>(c, l)) return;
+            if constexpr (SPLITK) {
+                if (attn_cu) {
+                    if (split) { if (!eg_attention<MASK, LEADER, true, true>(c, l)) return; }
+                    else { if (!eg_attention<MASK, LEADER, true, false>(c, l)) return; }
+                } else if (split) { if (!eg_attention<MASK, LEADER, false, true>(c, l)) return; }
+            } else {
+                if (attn_cu && !eg_attention<MASK, LEADER, true, false>(c, l)) return;
+            }
             eg_fresh(c);
             if constexpr (LEADER) eg_stamp(c, l, 3);
             if (!eg_run_kmajor<EG_OP_O, LEADER>(c, g0 + EG_S_QKV, EG_S_O, l, s0 + 1, eg_mb(c, l, EG_MB_AO), eg_epoch(c, l, 2), pre_o)) return;
@@ -794,7 +888,7 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
     }
 }
 
-template <bool MASK>
+template <bool MASK, bool SPLITK>
 __global__ __launch_bounds__(256, 1) void decode_engine_kernel(vcla_engine_args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char eg_lds[];
     EgMisc* m = reinterpret_cast<EgMisc*>(eg_lds + EG_MISC_OFF);
@@ -811,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void decode_engine_kernel(vcla_engine_args 
         c.a = &a; c.ring = eg_lds; c.xin = eg_lds + EG_RING_BYTES; c.m = m; c.state = state;
         c.w = wave - 1; c.lane = lane; c.cu = blockIdx.x; c.eb = (seq << 10) + 1u; c.pos = pos;
         if (a.fault && blockIdx.x == 7) return;                  // test hook: a workgroup that never publishes (tests/test_gpu_engine.py)
-        if (wave == 1) eg_consumer<MASK, true>(c); else eg_consumer<MASK, false>(c);
+        if (wave == 1) eg_consumer<MASK, true, SPLITK>(c); else eg_consumer<MASK, false, SPLITK>(c);
     }
 }
 
@@ -831,16 +925,18 @@ bool vcla_engine_geometry(int hidden, int heads, int inter, int vocab, int n_lay
 }
 
 int vcla_engine_launch(const vcla_engine_args* a, hipStream_t s) {
-    static bool attr_set[2][VCLA_MAX_DEVICES] = {};
-    if (a->key_mask) {
-        const int rc = vcla_raise_dyn_lds((const void*)decode_engine_kernel<true>, EG_LDS_BYTES, attr_set[1]);
-        if (rc) return rc;
-        decode_engine_kernel<true><<<EG_NCU, 256, EG_LDS_BYTES, s>>>(*a);
-    } else {
-        const int rc = vcla_raise_dyn_lds((const void*)decode_engine_kernel<false>, EG_LDS_BYTES, attr_set[0]);
-        if (rc) return rc;
-        decode_engine_kernel<false><<<EG_NCU, 256, EG_LDS_BYTES, s>>>(*a);
+    static bool attr_set[4][VCLA_MAX_DEVICES] = {};
+    // the kernel with the split attention only for caches that can outgrow split_min (a captured step is replayed at every position up to ctx_max)
+    const bool sk = a->split_min > 0 && a->ctx_max > a->split_min;
+#define EG_GO(MASK_, SK_, I_)                                                                                                  \
+    {                                                                                                                          \
+        const int rc = vcla_raise_dyn_lds((const void*)decode_engine_kernel<MASK_, SK_>, EG_LDS_BYTES, attr_set[I_]);          \
+        if (rc) return rc;                                                                                                     \
+        decode_engine_kernel<MASK_, SK_><<<EG_NCU, 256, EG_LDS_BYTES, s>>>(*a);                                                \
     }
+    if (a->key_mask) { if (sk) EG_GO(true, true, 3) else EG_GO(true, false, 1) }
+    else { if (sk) EG_GO(false, true, 2) else EG_GO(false, false, 0) }
+#undef EG_GO
     VCLA_CHECK_LAUNCH("decode_engine_kernel");
     return VCLA_OK;
 }
