@@ -6,8 +6,9 @@
 // HBM round trip, the drain) and the weight stream idles during the attention -- 2.66 ms per token for 13.4 GB = 63 % of the HBM peak although
 // the long GEMVs alone reach 74 %.  MI355X_MICROARCH.md ("engine-vs-launches", "prefetch-credit", "ldsdma-fill") measures the structure used here:
 //   * 256 workgroups, one per CU, 4 waves each: wave 0 is a LOADER, waves 1 - 3 are CONSUMERS;
-//   * the loader streams its CU's share of ALL weights of the step -- one contiguous region of the engine twin ("llama.engine.w", built by
-//     weights.add_engine_stream: [CU][slot][16 KiB] in consumption order) -- with non-temporal `global_load_lds_dwordx4` into an 8 x 16 KiB LDS
+//   * the loader streams its CU's share of ALL weights of the step -- its 16-KiB slots of the engine twin ("llama.engine.w", built by
+//     weights.add_engine_stream: [slot][CU][16 KiB] in consumption order; SLOT-major, so that the 256 loaders together sweep one moving window of HBM
+//     instead of 256 private regions: profiles/r06_engine_placement.txt) -- with non-temporal `global_load_lds_dwordx4` into a 9 x 16 KiB LDS
 //     ring.  It knows nothing about operators: it runs ahead across every dependency edge until the ring is full (the prefetch credit);
 //   * a consumer wave takes a landed slot, multiplies it against the operator's input vector (bf16 in registers / LDS, `v_dot2c_f32_bf16`),
 //     reduces over the wave and publishes the outputs;
@@ -15,7 +16,7 @@
 //     granule, swept by ONE consumer wave per CU with relaxed agent-scope loads until every tag matches -- the data is the flag, no fences;
 //   * while its CU sweeps, the loader keeps only one fill in flight (the sweep's loads queue behind the CU's own DMA);
 //   * the attention of head h runs on the consumers of CU 8 h + h % 8 (one per head, spread over the XCDs) while every loader keeps
-//     prefetching wo / wgu.
+//     prefetching wo / wgu; from args.split_min cached keys on, the 8 CUs of the head's group share the walk over its cache (eg_attention).
 // Row ownership (so that no operator needs more than the all-gather of its input vector): CU c owns q / k / v rows h*128 + s*16 .. + 15 of
 // head h = c / 8, s = c % 8; rows 16 c .. + 15 of o_proj and down_proj (so the residual of its outputs is what it produced itself two
 // operators earlier); SwiGLU units upc * c .. ; lm_head rows 2 s_lm c ...  down_proj's K dimension is stored in granule order (44 slots per
