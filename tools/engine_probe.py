@@ -135,11 +135,7 @@ def main():
     kd = (results["0"][2][..., :T + a.steps, :].float() - results["1"][2][..., :T + a.steps, :].float()).abs()
     print(f"K/V cache: max |diff| {kd.max().item():.4f} over the {T + a.steps} rows both paths wrote", flush=True)
     if a.timeline:
-        for thin in (1,):
-            os.environ["VCLA_ENGINE_THIN"] = str(thin)
-            print(f"--- VCLA_ENGINE_THIN={thin}")
-            timeline(m, lib, embeds, T, ctx_max, a)
-        del os.environ["VCLA_ENGINE_THIN"]
+        timeline(m, lib, embeds, T, ctx_max, a)
     if a.time > 0:
         for mode in ("0", "1", "0", "1"):
             os.environ["VCLA_ENGINE"] = mode

@@ -59,7 +59,6 @@ struct vcla_engine_args {
     int tail_step_base;
     int fault;                     // test hook (VCLA_ENGINE_FAULT=1): the consumers of CU 7 leave at once -- every wait on their outputs must run out, not hang
     int split_min;                 // contexts of at least this many cached keys split a head's attention over the 8 CUs of its group (0: never)
-    int thin;                      // loader keeps ONE fill in flight while its CU sweeps a mailbox (MI355X_MICROARCH.md gather-pass) / 0: never thins
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };
 

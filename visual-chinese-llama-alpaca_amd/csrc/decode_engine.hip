@@ -14,7 +14,7 @@
 //     reduces over the wave and publishes the outputs;
 //   * operator outputs travel between CUs as 8-byte {epoch tag, two bf16} granules: ONE relaxed agent-scope (sc1, write-through) store per
 //     granule, swept by ONE consumer wave per CU with relaxed agent-scope loads until every tag matches -- the data is the flag, no fences;
-//   * while its CU sweeps, the loader keeps only one fill in flight (the sweep's loads queue behind the CU's own DMA);
+//   * the loader never keeps more than two fills (32 KiB) in flight: a CU's mailbox polls queue behind its own DMA;
 //   * the attention of head h runs on the consumers of CU 8 h + h % 8 (one per head, spread over the XCDs) while every loader keeps
 //     prefetching wo / wgu; from args.split_min cached keys on, the 8 CUs of the head's group share the walk over its cache (eg_attention).
 // Row ownership (so that no operator needs more than the all-gather of its input vector): CU c owns q / k / v rows h*128 + s*16 .. + 15 of
@@ -44,7 +44,7 @@ struct EgMisc {                            // LDS words shared by the four waves
     unsigned xin_ready;                    // leader: sequence number of the operator whose input vector is staged
     unsigned cons_done[3];                 // consumer w: sequence number of the last operator it finished
     unsigned attn_ready, attn_done[3];
-    unsigned gathering;                    // leader: a mailbox sweep is running (the loader thins itself)
+    unsigned unused_;                      // (was: a flag that made the loader thin itself during sweeps; it now never keeps more than two fills in flight)
     unsigned fail;
     unsigned pad_[12];                     // the 32 words above are zeroed at kernel start
     float resid0[16], resid1[16];          // the CU's 16 rows of the layer input x / of x + o_proj(...) (bf16 values)
@@ -197,9 +197,7 @@ __device__ __forceinline__ bool eg_stage_norm(EgCtx& c, const unsigned long long
 #pragma unroll
         for (int k = 0; k < 32; ++k) v[k] = xi[c.lane + 64 * k];
     } else {
-        eg_st(&c.m->gathering, 1);
         const bool good = eg_sweep<2>(c, mb, epoch, v, 2048, 0x11);
-        eg_st(&c.m->gathering, 0);
         if (!good) return false;
     }
     float ss = 0.f;
@@ -529,18 +527,16 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         const int i0 = 2 * (lane & 31);                       // rotation index of this lane's pair
         const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * (D / 2) + i0);
         const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
-        eg_st(&m->gathering, 1);
         for (unsigned it = 0;; ++it) {
             const unsigned long long xq = eg_peek(mb, h * 64 + lane);
             const unsigned long long xk = OWNER ? eg_peek(mb, 2048 + h * 64 + lane) : xq, xv = OWNER ? eg_peek(mb, 4096 + h * 64 + lane) : xq;      // (a helper needs q only)
             qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
             const bool good = (unsigned)(xq >> 32) == ep && (unsigned)(xk >> 32) == ep && (unsigned)(xv >> 32) == ep;
             if (__all(good)) break;
-            if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
-            if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x31); eg_st(&m->gathering, 0); return false; }
+            if ((it & 15) == 15 && eg_ld(&m->fail)) return false;
+            if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x31); return false; }
             __builtin_amdgcn_s_sleep(2);
         }
-        eg_st(&m->gathering, 0);
         eg_stamp(c, layer, 10);
         const float c0 = Act<bf16_t>::rnd(cs.x), c1 = Act<bf16_t>::rnd(cs.y), s0 = Act<bf16_t>::rnd(sn.x), s1 = Act<bf16_t>::rnd(sn.y);
         const bool hi_half = lane >= 32;
@@ -680,7 +676,6 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
                 float rm = -INFINITY, rl = 0.f, ro[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ro[e] = 0.f;
-                eg_st(&m->gathering, 1);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int p = g + 4 * k;
@@ -702,8 +697,8 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
                             }
                         }
                         if (__all(good)) break;
-                        if ((it & 15) == 15 && eg_ld(&m->fail)) { eg_st(&m->gathering, 0); return false; }
-                        if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x35); eg_st(&m->gathering, 0); return false; }
+                        if ((it & 15) == 15 && eg_ld(&m->fail)) return false;
+                        if (it > EG_SPIN_GLB) { eg_fail(m, c.state, 0x35); return false; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     const float mn_ = fmaxf(rm, pm);
@@ -713,7 +708,6 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ro[e] = ro[e] * a0 + po[e] * a1;
                 }
-                eg_st(&m->gathering, 0);
                 mf = rm; lf = rl;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = ro[e];
@@ -876,9 +870,11 @@ __device__ __forceinline__ void eg_loader(const vcla_engine_args& a, unsigned ri
         const unsigned char* s = src + (size_t)g * slot_stride;
 #pragma unroll
         for (int i = 0; i < 16; ++i) eg_dma16_nt(s + i * 1024, dst + i * 1024);
-        unsigned landed;
-        if (a.thin && eg_ld(&m->gathering)) { eg_vmcnt<16>(); landed = g; }          // thin: at most this fill in flight while the CU sweeps a mailbox
-        else { eg_vmcnt<48>(); landed = g >= 2 ? g - 2 : 0; }              // slots <= g - 3 have landed
+        // ONE fill behind the one just issued: with the slot-major stream HBM answers in ~1 us, 16 - 32 KiB in flight per CU keep it busy, and every
+        // further miss in flight only delays the CU's own mailbox polls.  Per token on one box (vmcnt 0 / 8 / 12 / 16 / 20 / 32 / 48): 3.10 / 2.74 / 2.57 /
+        // 2.13 - 2.17 / 2.15 / 2.15 - 2.18 / 2.19 - 2.22 ms.  (The CU-major stream wanted three fills in flight and a thinner loader during sweeps.)
+        eg_vmcnt<16>();
+        const unsigned landed = g;                                        // slots < g have landed
         if (landed > pub) { pub = landed; eg_st(&m->filled, pub); }
     }
     eg_vmcnt<0>();

@@ -927,7 +927,6 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
             ea.tail_pos = pos_dev; ea.tail_step_base = loop_step_base;
         }
         if (tail_folded) *tail_folded = fold;
-        { const char* e_ = getenv("VCLA_ENGINE_THIN"); ea.thin = e_ ? atoi(e_) : 1; }
         { const char* e_ = getenv("VCLA_ENGINE_SPLIT"); ea.split_min = e_ ? atoi(e_) : 512; }      // VCLA_ENGINE_SPLIT=0: one CU per head at every context
         { const char* e_ = getenv("VCLA_ENGINE_FAULT"); ea.fault = e_ ? atoi(e_) : 0; }            // test hook, see decode_engine.h
         if (const char* tl = getenv("VCLA_ENGINE_TL")) ea.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);   // debug: tools/engine_probe.py --timeline
