@@ -64,7 +64,8 @@ def timeline(m, lib, embeds, T, ctx_max, a):
     full = t[:, :L * 16].view(256, L, 16)
     sa = full[attn][:, lay]
     print(f"  inside the attention (attention CUs, leader wave): qkv done -> q/k/v granules complete {(sa[..., 10] - sa[..., 2]).median():.2f} | RoPE, cache append, LDS "
-          f"{(sa[..., 11] - sa[..., 10]).median():.2f} | scores + PV over the cache {(sa[..., 12] - sa[..., 11]).median():.2f} | wait for the other waves, merge, publish "
+          f"{(sa[..., 11] - sa[..., 10]).median():.2f} | scores + PV over the cache {(sa[..., 12] - sa[..., 11]).median():.2f} (the key batches {(sa[..., 13] - sa[..., 11]).median():.2f}, "
+          f"the new token + the wave's 4 lane groups {(sa[..., 14] - sa[..., 13]).median():.2f}, share to LDS {(sa[..., 12] - sa[..., 14]).median():.2f}) | wait for the other waves, merge, publish "
           f"{(sa[..., 3] - sa[..., 12]).median():.2f}")
     per_layer = (st[:, lay, -1] - st[:, lay, 0])
     print(f"  layer, stamp 0 -> 9: median {per_layer.median():.2f} us, max {per_layer.max():.2f} us; whole step (loader begin -> end): "

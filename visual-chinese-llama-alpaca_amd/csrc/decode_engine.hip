@@ -600,6 +600,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     }
 #undef EG_FD_LOAD
 #undef EG_FD_COMPUTE
+    if constexpr (LEADER) eg_stamp(c, layer, 13);
     if constexpr (OWNER) {   // the new token (key / value in LDS): every group computes it, group 0 of the owner's workgroup folds it in
         float d_ = 0.f;
 #pragma unroll
@@ -629,6 +630,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         for (int e = 0; e < 8; ++e) o[e] = o[e] * a1 + __shfl_xor(o[e], off, 64) * a2;
         m_run = mn_;
     }
+    if constexpr (LEADER) eg_stamp(c, layer, 14);
     if (lane < LPK) {
         float* pw = m->part[c.w];
 #pragma unroll
