@@ -58,7 +58,6 @@ struct vcla_engine_args {
     int32_t* tail_pos;
     int tail_step_base;
     int fault;                     // test hook (VCLA_ENGINE_FAULT=1): the consumers of CU 7 leave at once -- every wait on their outputs must run out, not hang
-    int poll_first;                // the attention leader's first q / k / v poll is issued BEFORE its share of the cache rows is requested (answers return in order)
     int split_min;                 // contexts of at least this many cached keys split a head's attention over the 8 CUs of its group (0: never)
     unsigned long long* timeline;  // debug (tools/engine_probe.py --timeline): [256 CUs][EG_TL_STRIDE] wall-clock stamps (100 MHz), or NULL
 };

@@ -513,7 +513,7 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);
     const int nb = (pos + U * KPB - 1) / (U * KPB);
-    if (nb > 0 && !(LEADER && a.poll_first)) {            // the cache rows do not depend on this step's q: requested before the qkv granules are even complete
+    if (nb > 0) {            // the cache rows do not depend on this step's q: requested before the qkv granules are even complete
         EG_FD_LOAD(kA, vA, mA, 0)
         EG_FD_LOAD(kB, vB, mB, 1)
     }
@@ -530,11 +530,6 @@ __device__ __forceinline__ bool eg_attention(EgCtx& c, int layer) {
         for (unsigned it = 0;; ++it) {
             const unsigned long long xq = eg_peek(mb, h * 64 + lane);
             const unsigned long long xk = OWNER ? eg_peek(mb, 2048 + h * 64 + lane) : xq, xv = OWNER ? eg_peek(mb, 4096 + h * 64 + lane) : xq;      // (a helper needs q only)
-            if (it == 0 && nb > 0 && a.poll_first) {        // the first poll is in flight BEFORE this wave's share of the cache rows is requested: loads return in order, and a
-                                                            // poll behind 32 row requests learns 1 - 1.5 us late that the granules were there (2.14 vs 2.17 ms per step)
-                EG_FD_LOAD(kA, vA, mA, 0)
-                EG_FD_LOAD(kB, vB, mB, 1)
-            }
             qd = (unsigned)xq; kd = (unsigned)xk; vd = (unsigned)xv;
             const bool good = (unsigned)(xq >> 32) == ep && (unsigned)(xk >> 32) == ep && (unsigned)(xv >> 32) == ep;
             if (__all(good)) break;

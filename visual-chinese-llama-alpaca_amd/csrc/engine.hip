@@ -928,7 +928,6 @@ static int decode_step_impl(vcla_ctx* ctx, hipStream_t s, const int64_t* ids_in,
         }
         if (tail_folded) *tail_folded = fold;
         { const char* e_ = getenv("VCLA_ENGINE_SPLIT"); ea.split_min = e_ ? atoi(e_) : 512; }      // VCLA_ENGINE_SPLIT=0: one CU per head at every context
-        { const char* e_ = getenv("VCLA_ENGINE_POLL1"); ea.poll_first = e_ ? atoi(e_) : 1; }       // VCLA_ENGINE_POLL1=0: the attention leader requests its cache rows before its first poll (A/B)
         { const char* e_ = getenv("VCLA_ENGINE_FAULT"); ea.fault = e_ ? atoi(e_) : 0; }            // test hook, see decode_engine.h
         if (const char* tl = getenv("VCLA_ENGINE_TL")) ea.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);   // debug: tools/engine_probe.py --timeline
         RUN(vcla_engine_launch(&ea, s));
